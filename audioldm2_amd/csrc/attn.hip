@@ -1,0 +1,151 @@
+// attn.hip — multi-head attention with head dim 32 (every UNet attention: attention.py:343-367),
+// flash-style online softmax on fp32 MFMA 32x32x2.  No score matrix ever reaches HBM (the
+// reference materialises 8x1024x1024 fp32 = 32 MB per layer per sample).
+//
+// Wave-level dataflow (one wave64 = 32 queries, all operands stay in registers):
+//   S^T = K * Q^T   (A = K rows (keys), B = Q^T)   -> lane (query = lane&31, half = lane>>5) holds the
+//                                                      scores of its query against 16 keys of the tile
+//   softmax is therefore lane-local + one xor-32 exchange (no LDS, no transposes),
+//   O^T += V^T * P^T (A = V^T, B = P^T = the score registers as they are)
+//                                                   -> lane holds 16 output dims of ITS query, so the
+//                                                      online-softmax rescale is lane-local too.
+// The K-index permutation inside each MFMA is free (d index s pairs with 16+s; key (r&3)+8(r>>2)
+// pairs with the same +4), which is what makes both products transpose-free.
+#include "common.h"
+#include <float.h>
+
+namespace aldm {
+
+__global__ __launch_bounds__(256) void attention_d32_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+    const float* __restrict__ mask, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= Lq) return;  // wave-uniform
+
+    // Q fragment: Q[q0 + l31][h*32 + 16*lh + s], pre-scaled
+    float qf[16];
+    {
+        const int qi = q0 + l31;
+        const float* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32 + 16 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (qi < Lq) t = *reinterpret_cast<const f32x4*>(qp + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[4 * g + e] = t[e] * scale;
+        }
+    }
+
+    f32x16 oT;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oT[e] = 0.f;
+    float m_run = -INFINITY;
+    float l_run = 0.f;  // this lane's half of the row sum
+
+    const float* kb = k + (int64_t)b * Lk * ldk + h * 32;
+    const float* vb = v + (int64_t)b * Lk * ldv + h * 32;
+    const float* mb = mask ? mask + (int64_t)b * Lk : nullptr;
+
+    for (int j0 = 0; j0 < Lk; j0 += 32) {
+        // K fragment (A operand): K[j0 + l31][16*lh + s]
+        float kf[16];
+        {
+            const int kj = j0 + l31;
+            const float* kp = kb + (int64_t)kj * ldk + 16 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (kj < Lk) t = *reinterpret_cast<const f32x4*>(kp + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kf[4 * g + e] = t[e];
+            }
+        }
+        // V^T fragment (A operand of the second product): V[j0 + key(r)][dd = l31]
+        float vf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            vf[r] = kj < Lk ? vb[(int64_t)kj * ldv + l31] : 0.f;
+        }
+
+        f32x16 st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], st, 0, 0, 0);
+
+        // masking: out-of-range keys are excluded (-inf); masked keys get -FLT_MAX exactly as
+        // masked_fill_(~(mask == 1), -finfo.max) does in the reference
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float sv = st[r];
+            if (kj >= Lk) sv = -INFINITY;
+            else if (mb && mb[kj] != 1.0f) sv = -FLT_MAX;
+            st[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = expf(st[r] - m_new);
+            st[r] = pv;
+            psum += pv;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[e] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            oT = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], oT, 0, 0, 0);
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + l31;
+    if (qi < Lq) {
+        float* op = out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = oT[4 * g + e] * inv;
+            *reinterpret_cast<f32x4*>(op + 8 * g) = t;
+        }
+    }
+}
+
+}  // namespace aldm
+
+using namespace aldm;
+
+extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v, float* out, int B,
+                                  int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                                  const float* mask, float scale, void* stream) {
+    ALDM_CHECK(q && k && v && out, "aldm_attention_d32: null pointer");
+    ALDM_CHECK(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "aldm_attention_d32: bad sizes");
+    ALDM_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0 && ldq >= heads * 32 &&
+                   ldk >= heads * 32 && ldv >= heads * 32 && ldo >= heads * 32,
+               "aldm_attention_d32: row pitches must be multiples of 4 and >= heads*32");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                 reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+               "aldm_attention_d32: q/k/out must be 16-byte aligned");
+    dim3 grid(cdiv(Lq, 128), heads, B);
+    hipLaunchKernelGGL(attention_d32_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, Lq,
+                       Lk, ldq, ldk, ldv, ldo, mask, scale);
+    ALDM_LAUNCH_CHECK("aldm_attention_d32");
+    return 0;
+}

@@ -1,0 +1,255 @@
+// norm.hip — GroupNorm statistics (-> per-(sample, channel) affine consumed by the igemm prologue),
+// LayerNorm, row softmax.  All HBM-bound: one coalesced 16-byte read per element, fp32 math,
+// deterministic reduction order (no atomics).
+#include "common.h"
+
+namespace aldm {
+
+// ---- GroupNorm -------------------------------------------------------------------------------
+// x = x1 ++ x2 (channels-last, [B, P, C1] / [B, P, C2]); G groups of Cg = C/G channels, Cg % 4 == 0
+// so each float4 column belongs to exactly one group.
+// Pass 1: grid (chunks, B).  Thread (tx, ty): float4 column tx (+ 256-strided extra columns when
+//         C/4 > 256), pixels p0 + ty + rows*i.  Per-thread (sum, sumsq) -> LDS -> one thread per
+//         group adds the group's thread partials in a fixed order -> ws[b][chunk][g] = {sum, sumsq}.
+// Pass 2: grid (B).  double-precision combine of the chunk partials, mean/rstd, then
+//         scale[b,c] = rstd*gamma[c], shift[b,c] = beta[c] - mean*rstd*gamma[c].
+constexpr int GN_ITERS = 16;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x1,
+                                                         const float* __restrict__ x2, int P,
+                                                         int C1, int C2, int G, int cols, int rows,
+                                                         int chunk_px, float* __restrict__ ws) {
+    const int C = C1 + C2;
+    const int C4 = C >> 2;
+    const int Cg4 = (C / G) >> 2;
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int p0 = chunk * chunk_px;
+    const int p1 = min(P, p0 + chunk_px);
+    const int tid = threadIdx.x;
+    const int tx = tid % cols, ty = tid / cols;
+    __shared__ float ps[256][2];
+    // columns handled in passes of `cols` (cols = min(C4, 256))
+    const int npass = (C4 + cols - 1) / cols;
+    for (int g = tid; g < 2 * G; g += 256) ws[((int64_t)(b * gridDim.x + chunk) * G) * 2 + g] = 0.f;
+    __syncthreads();
+    for (int cp = 0; cp < npass; ++cp) {
+        const int c4 = cp * cols + tx;
+        float s = 0.f, ss = 0.f;
+        if (ty < rows && c4 < C4) {
+            const int c = c4 << 2;
+            const bool first = c < C1;
+            const float* src = first ? x1 + (int64_t)b * P * C1 + c : x2 + (int64_t)b * P * C2 + (c - C1);
+            const int pitch = first ? C1 : C2;
+            for (int p = p0 + ty; p < p1; p += rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)p * pitch);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+                ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+        ps[tid][0] = s;
+        ps[tid][1] = ss;
+        __syncthreads();
+        // groups touched by this column pass: c4 in [cp*cols, cp*cols+cols)
+        // one thread per (group) sums, in fixed order, all (tx, ty) of that group.
+        if (tid < G) {
+            const int g = tid;
+            const int lo = max(g * Cg4, cp * cols), hi = min((g + 1) * Cg4, min(C4, (cp + 1) * cols));
+            if (lo < hi) {
+                float a = 0.f, a2 = 0.f;
+                for (int yy = 0; yy < rows; ++yy)
+                    for (int cc = lo; cc < hi; ++cc) {
+                        const int t = yy * cols + (cc - cp * cols);
+                        a += ps[t][0];
+                        a2 += ps[t][1];
+                    }
+                float* w = ws + ((int64_t)(b * gridDim.x + chunk) * G + g) * 2;
+                w[0] += a;
+                w[1] += a2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, int chunks,
+                                                          int P, int C, int G, float eps,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+    const int b = blockIdx.x;
+    __shared__ float s_mean[64], s_rstd[64];
+    const int Cg = C / G;
+    if (threadIdx.x < G) {
+        const int g = threadIdx.x;
+        double s = 0.0, ss = 0.0;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const float* w = ws + ((int64_t)(b * chunks + ch) * G + g) * 2;
+            s += (double)w[0];
+            ss += (double)w[1];
+        }
+        const double n = (double)P * Cg;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / Cg;
+        const float ga = gamma ? gamma[c] : 1.f;
+        const float be = beta ? beta[c] : 0.f;
+        const float sc = s_rstd[g] * ga;
+        scale[(int64_t)b * C + c] = sc;
+        shift[(int64_t)b * C + c] = be - s_mean[g] * sc;
+    }
+}
+
+// ---- LayerNorm: one wave64 per row, row kept in registers (C <= 2048), exact two-pass ---------
+constexpr int LN_MAXV = 8;
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ y, int M, int C,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int C4 = C >> 2;
+    const float* xr = x + (int64_t)row * C;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < C4) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < C4) {
+            const f32x4 dlt = v[i] - mean;
+            q += (dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    float* yr = y + (int64_t)row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < C4) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+            const f32x4 o = (v[i] - mean) * rstd * ga + be;
+            *reinterpret_cast<f32x4*>(yr + 4 * c4) = o;
+        }
+    }
+}
+
+// ---- row softmax (VAE mid attention, 4096-wide rows): one block per row, row staged in LDS ----
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int N,
+                                                           float scale) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const float* xr = x + row * N;
+    float* yr = y + row * N;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        const float v = xr[i] * scale;
+        srow[i] = v;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        const float e = expf(srow[i] - mx);
+        srow[i] = e;
+        s += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / s;
+    for (int i = tid; i < N; i += 256) yr[i] = srow[i] * inv;
+}
+
+static void gn_geometry(int P, int C, int* cols, int* rows, int* chunk_px, int* chunks) {
+    const int C4 = C / 4;
+    *cols = C4 < 256 ? C4 : 256;
+    *rows = 256 / *cols;
+    if (*rows < 1) *rows = 1;
+    *chunk_px = *rows * GN_ITERS;
+    *chunks = (P + *chunk_px - 1) / *chunk_px;
+}
+
+}  // namespace aldm
+
+using namespace aldm;
+
+extern "C" int64_t aldm_gn_ws_floats(int B, int P, int C, int G) {
+    int cols, rows, chunk_px, chunks;
+    gn_geometry(P, C, &cols, &rows, &chunk_px, &chunks);
+    return (int64_t)B * chunks * G * 2;
+}
+
+extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1, int C2,
+                                    int G, float eps, const float* gamma, const float* beta,
+                                    float* scale, float* shift, float* ws, void* stream) {
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    ALDM_CHECK(x1 && scale && shift && ws, "aldm_groupnorm_stats: null pointer");
+    ALDM_CHECK(G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && C1 % 4 == 0,
+               "aldm_groupnorm_stats: need C%%G==0, (C/G)%%4==0, C1%%4==0 (C1=%d C2=%d G=%d)", C1, C2, G);
+    int cols, rows, chunk_px, chunks;
+    gn_geometry(P, C, &cols, &rows, &chunk_px, &chunks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(256), 0, st, x1, x2, P, C1, C2, G,
+                       cols, rows, chunk_px, ws);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, ws, chunks, P, C, G, eps, gamma,
+                       beta, scale, shift);
+    ALDM_LAUNCH_CHECK("aldm_groupnorm_stats");
+    return 0;
+}
+
+extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
+                              const float* beta, float eps, void* stream) {
+    ALDM_CHECK(x && y && gamma && beta, "aldm_layernorm: null pointer");
+    ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "aldm_layernorm: C=%d must be a multiple of 4 and <= %d",
+               C, 256 * LN_MAXV);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, y, M,
+                       C, gamma, beta, eps);
+    ALDM_LAUNCH_CHECK("aldm_layernorm");
+    return 0;
+}
+
+extern "C" int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale,
+                                 void* stream) {
+    ALDM_CHECK(x && y && M > 0 && N > 0, "aldm_softmax_rows: bad args");
+    ALDM_CHECK((int64_t)N * 4 <= 60 * 1024, "aldm_softmax_rows: row of %d floats exceeds the 60 KiB LDS stage", N);
+    ALDM_CHECK(M < (1ll << 31), "aldm_softmax_rows: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), (size_t)N * 4,
+                       (hipStream_t)stream, x, y, N, scale);
+    ALDM_LAUNCH_CHECK("aldm_softmax_rows");
+    return 0;
+}

@@ -1,0 +1,113 @@
+"""ctypes binding of libaldm_hip.so (the C ABI declared in include/aldm_hip.h).
+
+The library is the product: there is NO CPU / PyTorch fallback behind these bindings.  If the
+shared object is missing or a call fails, a RuntimeError is raised (the reference's convention is
+plain Python exceptions, e.g. openaimodel.py:858-860).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaldm_hip.so")
+ABI_VERSION = 1
+
+ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
+B_PACKED, B_NT = 0, 1
+
+
+class IgemmDesc(C.Structure):
+    """Mirror of `struct aldm_igemm_desc` (include/aldm_hip.h) — keep field order identical."""
+
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p),
+        ("C1", C.c_int32), ("C2", C.c_int32),
+        ("pix1", C.c_int32), ("pix2", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("up_h", C.c_int32), ("up_w", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("SH", C.c_int32), ("SW", C.c_int32),
+        ("PH", C.c_int32), ("PW", C.c_int32), ("DH", C.c_int32), ("DW", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p),
+        ("pre_act", C.c_int32), ("pre_slope", C.c_float),
+        ("w", C.c_void_p),
+        ("b_mode", C.c_int32), ("ldb", C.c_int32),
+        ("K", C.c_int32), ("N", C.c_int32),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
+        ("ldo", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float), ("alpha", C.c_float),
+        ("accumulate", C.c_int32),
+        ("out_mul", C.c_int32), ("out_off", C.c_int32), ("out_len", C.c_int32),
+        ("batch", C.c_int32),
+        ("stride_x", C.c_int64), ("stride_w", C.c_int64), ("stride_o", C.c_int64),
+    ]
+
+
+_SIGS = {
+    "aldm_version": (C.c_int, []),
+    "aldm_last_error": (C.c_char_p, []),
+    "aldm_igemm": (C.c_int, [C.POINTER(IgemmDesc), C.c_void_p]),
+    "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "aldm_pack_kn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int64, C.c_int64, C.c_void_p]),
+    "aldm_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aldm_gn_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_float, C.c_void_p]),
+    "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_float, C.c_void_p]),
+    "aldm_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
+                                    C.c_void_p]),
+    "aldm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "aldm_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                          C.c_void_p]),
+    "aldm_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p]),
+    "aldm_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "aldm_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    "aldm_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64,
+                             C.c_void_p]),
+    "aldm_reflect_pad_1d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    "aldm_mag_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p]),
+}
+
+# every symbol include/aldm_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+_lib = None
+
+
+def load():
+    """Load libaldm_hip.so once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP kernel library has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C audioldm2_amd/csrc`). "
+            "There is no CPU fallback for the sampling hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.aldm_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError(f"libaldm_hip.so ABI version {ver} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().aldm_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libaldm_hip {what} failed ({rc}): {msg}")

@@ -1,0 +1,375 @@
+"""Thin tensor-level wrappers over the C ABI (lib.py).  PyTorch is plumbing here: device memory,
+the current HIP stream and nothing else — every FLOP of the hot path runs in libaldm_hip.so.
+
+Layout convention: activations are channels-last fp32, `[B, H, W, C]` (2-D) or `[B, 1, L, C]` (1-D).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _l
+from .lib import (ACT_GELU, ACT_LOGCLAMP, ACT_LRELU, ACT_NONE, ACT_SILU, ACT_TANH, B_NT, B_PACKED,
+                  IgemmDesc)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous fp32 CUDA tensor, got "
+                           f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+@dataclass
+class Packed:
+    """A weight re-laid-out once for the igemm B operand: [ceil(K/4)][Npad][4]."""
+    data: torch.Tensor
+    N: int
+    Cin: int
+    KH: int
+    KW: int
+    bias: Optional[torch.Tensor] = None
+
+    @property
+    def K(self) -> int:
+        return self.KH * self.KW * self.Cin
+
+
+def _npad(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> Packed:
+    """weight: Linear [N, Cin], Conv1d [N, Cin, KW] or Conv2d [N, Cin, KH, KW] (PyTorch layouts)."""
+    w = weight.detach().to(device="cuda", dtype=torch.float32).contiguous()
+    if w.dim() == 2:
+        N, Cin, KH, KW = w.shape[0], w.shape[1], 1, 1
+    elif w.dim() == 3:
+        N, Cin, KH, KW = w.shape[0], w.shape[1], 1, w.shape[2]
+    else:
+        N, Cin, KH, KW = w.shape
+    K = KH * KW * Cin
+    dst = torch.empty(((K + 3) // 4) * _npad(N) * 4, device="cuda", dtype=torch.float32)
+    lib = _l.load()
+    _l.check(lib.aldm_pack_weight(w.data_ptr(), dst.data_ptr(), N, Cin, KH, KW, 0, 0, 1, _stream()),
+             "pack_weight")
+    b = None if bias is None else bias.detach().to(device="cuda", dtype=torch.float32).contiguous()
+    return Packed(dst, N, Cin, KH, KW, b)
+
+
+def pack_convtr1d(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int) -> List[Packed]:
+    """ConvTranspose1d weight [Cin, N, K] -> one Packed per output phase (polyphase decomposition)."""
+    w = weight.detach().to(device="cuda", dtype=torch.float32).contiguous()
+    Cin, N, KW = w.shape
+    T = (KW + stride - 1) // stride
+    lib = _l.load()
+    b = None if bias is None else bias.detach().to(device="cuda", dtype=torch.float32).contiguous()
+    out = []
+    for ph in range(stride):
+        dst = torch.empty(((T * Cin + 3) // 4) * _npad(N) * 4, device="cuda", dtype=torch.float32)
+        _l.check(lib.aldm_pack_weight(w.data_ptr(), dst.data_ptr(), N, Cin, 1, KW, 1, ph, stride,
+                                      _stream()), "pack_weight(tr)")
+        out.append(Packed(dst, N, Cin, 1, T, b))
+    return out
+
+
+def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), up=(1, 1),
+         x2: Optional[torch.Tensor] = None, out_hw: Optional[Tuple[int, int]] = None,
+         pre: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, pre_act: int = ACT_NONE,
+         pre_slope: float = 0.0, bias: Optional[torch.Tensor] = None,
+         rowbias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, act_slope: float = 0.0, alpha: float = 1.0,
+         out: Optional[torch.Tensor] = None, accumulate: bool = False,
+         remap: Optional[Tuple[int, int, int]] = None,
+         use_pw_bias: bool = True) -> torch.Tensor:
+    """Implicit-GEMM convolution (aldm_igemm).  x: [B, H, W, C1] (+ x2: [B, H, W, C2] concatenated
+    along C).  Returns [B, OH, OW, N] (or the remapped [B, 1, out_len, N])."""
+    _chk(x, "conv.x")
+    B, H, W, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "conv.x2")
+        assert x2.shape[:3] == x.shape[:3]
+        C2 = x2.shape[3]
+    assert C1 + C2 == pw.Cin, f"channels {C1}+{C2} != packed Cin {pw.Cin}"
+    VH, VW = H * up[0], W * up[1]
+    if out_hw is None:
+        OH = (VH + 2 * pad[0] - dil[0] * (pw.KH - 1) - 1) // stride[0] + 1
+        OW = (VW + 2 * pad[1] - dil[1] * (pw.KW - 1) - 1) // stride[1] + 1
+    else:
+        OH, OW = out_hw
+    N = pw.N
+    if remap is not None:
+        out_mul, out_off, out_len = remap
+        oshape = (B, 1, out_len, N)
+    else:
+        out_mul = out_off = out_len = 0
+        oshape = (B, OH, OW, N)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "conv.out")
+        assert out.numel() == oshape[0] * oshape[1] * oshape[2] * oshape[3], (out.shape, oshape)
+    if bias is None and use_pw_bias:
+        bias = pw.bias
+    d = IgemmDesc()
+    d.x1 = x.data_ptr(); d.x2 = _p(x2)
+    d.C1 = C1; d.C2 = C2; d.pix1 = 0; d.pix2 = 0
+    d.B = B; d.H = H; d.W = W; d.up_h = up[0]; d.up_w = up[1]
+    d.KH = pw.KH; d.KW = pw.KW; d.SH = stride[0]; d.SW = stride[1]
+    d.PH = pad[0]; d.PW = pad[1]; d.DH = dil[0]; d.DW = dil[1]
+    d.OH = OH; d.OW = OW
+    if pre is not None:
+        d.pre_scale = pre[0].data_ptr(); d.pre_shift = pre[1].data_ptr()
+    d.pre_act = pre_act; d.pre_slope = pre_slope
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
+    d.K = pw.K; d.N = N
+    d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = out.data_ptr()
+    d.ldo = N; d.act = act; d.act_slope = act_slope; d.alpha = alpha
+    d.accumulate = 1 if accumulate else 0
+    d.out_mul = out_mul; d.out_off = out_off; d.out_len = out_len
+    d.batch = 1
+    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(conv)")
+    return out.view(oshape)
+
+
+def linear(x: torch.Tensor, pw: Packed, **kw) -> torch.Tensor:
+    """x: [..., Cin] -> [..., N] through the same engine (1x1 'conv' over M rows)."""
+    shp = x.shape
+    M = x.numel() // shp[-1]
+    y = conv(x.reshape(1, 1, M, shp[-1]), pw, **kw)
+    return y.view(*shp[:-1], pw.N)
+
+
+def gemm_nt(a: torch.Tensor, bmat: torch.Tensor, *, alpha: float = 1.0,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batched C[z] = alpha * A[z] @ Bmat[z]^T with A [Z, M, K], Bmat [Z, N, K] (activation x
+    activation product: Q K^T of the VAE mid attention, model.py:219)."""
+    _chk(a, "gemm_nt.a"); _chk(bmat, "gemm_nt.b")
+    Z, M, K = a.shape
+    Zb, N, Kb = bmat.shape
+    assert Z == Zb and K == Kb and K % 4 == 0
+    if out is None:
+        out = torch.empty((Z, M, N), device=a.device, dtype=torch.float32)
+    d = IgemmDesc()
+    d.x1 = a.data_ptr(); d.C1 = K; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
+    d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
+    d.OH = 1; d.OW = M
+    d.w = bmat.data_ptr(); d.b_mode = B_NT; d.ldb = K; d.K = K; d.N = N
+    d.out = out.data_ptr(); d.ldo = N; d.alpha = alpha
+    d.batch = Z; d.stride_x = M * K; d.stride_w = N * K; d.stride_o = M * N
+    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(nt)")
+    return out
+
+
+def pack_kn(src: torch.Tensor) -> torch.Tensor:
+    """[Z, K, N] row-major activations -> packed B operand [Z][ceil(K/4)][Npad][4]."""
+    _chk(src, "pack_kn.src")
+    Z, K, N = src.shape
+    per = ((K + 3) // 4) * _npad(N) * 4
+    dst = torch.empty((Z, per), device=src.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_pack_kn(src.data_ptr(), dst.data_ptr(), K, N, N, Z, K * N, per, _stream()),
+             "pack_kn")
+    return dst
+
+
+def gemm_packed_batched(a: torch.Tensor, bp: torch.Tensor, K: int, N: int, *,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batched C[z] = A[z] @ B[z], B pre-packed by pack_kn (P V of the VAE mid attention)."""
+    _chk(a, "gemm_packed.a")
+    Z, M, Ka = a.shape
+    assert Ka == K and K % 4 == 0
+    if out is None:
+        out = torch.empty((Z, M, N), device=a.device, dtype=torch.float32)
+    d = IgemmDesc()
+    d.x1 = a.data_ptr(); d.C1 = K; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
+    d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
+    d.OH = 1; d.OW = M
+    d.w = bp.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0; d.K = K; d.N = N
+    d.out = out.data_ptr(); d.ldo = N; d.alpha = 1.0
+    d.batch = Z; d.stride_x = M * K; d.stride_w = bp.shape[1]; d.stride_o = M * N
+    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(packed batched)")
+    return out
+
+
+_gn_ws = {}
+
+
+def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int = 32,
+             eps: float = 1e-5, x2: Optional[torch.Tensor] = None):
+    """GroupNorm statistics of channels-last x (++ x2) -> (scale, shift), each [B, C]."""
+    _chk(x, "gn.x")
+    B = x.shape[0]
+    C1 = x.shape[-1]
+    P = x.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "gn.x2")
+        C2 = x2.shape[-1]
+    Cc = C1 + C2
+    lib = _l.load()
+    nws = lib.aldm_gn_ws_floats(B, P, Cc, groups)
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+    ss = torch.empty((2, B, Cc), device=x.device, dtype=torch.float32)
+    _l.check(lib.aldm_groupnorm_stats(x.data_ptr(), _p(x2), B, P, C1, C2, groups, eps,
+                                      gamma.data_ptr(), beta.data_ptr(), ss[0].data_ptr(),
+                                      ss[1].data_ptr(), ws.data_ptr(), _stream()), "groupnorm_stats")
+    return ss[0], ss[1]
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    _chk(x, "ln.x")
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_layernorm(x.data_ptr(), y.data_ptr(), M, Cc, gamma.data_ptr(),
+                                      beta.data_ptr(), eps, _stream()), "layernorm")
+    return y
+
+
+def _rowview(t: torch.Tensor, name: str):
+    """[B, L, D] view (possibly a column slice of a wider contiguous buffer) -> (ptr, L, row pitch)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1
+            and t.stride(0) == t.shape[1] * t.stride(1)):
+        raise RuntimeError(f"{name}: need [B, L, D] fp32 CUDA view with unit inner stride")
+    return t.data_ptr(), t.shape[1], t.stride(1)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *,
+              mask: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(scale * q k^T [mask]) v per head, head dim 32.  q: [B, Lq, heads*32] views."""
+    qp, Lq, ldq = _rowview(q, "attn.q")
+    kp, Lk, ldk = _rowview(k, "attn.k")
+    vp, Lv, ldv = _rowview(v, "attn.v")
+    assert Lk == Lv and q.shape[2] == heads * 32
+    B = q.shape[0]
+    if scale is None:
+        scale = 32 ** -0.5
+    out = torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
+    if mask is not None:
+        mask = mask.to(torch.float32).reshape(B, Lk).contiguous()
+    _l.check(_l.load().aldm_attention_d32(qp, kp, vp, out.data_ptr(), B, heads, Lq, Lk, ldq, ldk, ldv,
+                                          heads * 32, _p(mask), scale, _stream()), "attention_d32")
+    return out
+
+
+def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    _chk(x, "softmax.x")
+    N = x.shape[-1]
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_softmax_rows(x.data_ptr(), y.data_ptr(), x.numel() // N, N, scale,
+                                         _stream()), "softmax_rows")
+    return y
+
+
+def geglu(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "geglu.x")
+    C2 = x.shape[-1]
+    M = x.numel() // C2
+    y = torch.empty((*x.shape[:-1], C2 // 2), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_geglu(x.data_ptr(), y.data_ptr(), M, C2 // 2, _stream()), "geglu")
+    return y
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim,
+                                               max_period, _stream()), "timestep_embedding")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor, rep: int = 1) -> torch.Tensor:
+    _chk(x, "nchw_to_nhwc.x")
+    B, Cc, H, W = x.shape
+    y = torch.empty((rep * B, H, W, Cc), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, Cc, H * W, rep, _stream()),
+             "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, "nhwc_to_nchw.x")
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), B, Cc, H * W, _stream()),
+             "nhwc_to_nchw")
+    return y
+
+
+def ddim_step(x: torch.Tensor, eps: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor,
+              x_prev: Optional[torch.Tensor] = None, pred_x0: Optional[torch.Tensor] = None):
+    """Fused CFG combine + DDIM update.  eps: [2, *x.shape] (uncond, cond) or [*x.shape]."""
+    for t, n in ((x, "x"), (eps, "eps"), (noise, "noise"), (coef, "coef")):
+        _chk(t, "ddim." + n)
+    if x_prev is None:
+        x_prev = torch.empty_like(x)
+    if pred_x0 is None:
+        pred_x0 = torch.empty_like(x)
+    _l.check(_l.load().aldm_ddim_step(x.data_ptr(), eps.data_ptr(), noise.data_ptr(), coef.data_ptr(),
+                                      x_prev.data_ptr(), pred_x0.data_ptr(), x.numel(), _stream()),
+             "ddim_step")
+    return x_prev, pred_x0
+
+
+def axpby(a: torch.Tensor, b: Optional[torch.Tensor], alpha: float, beta: float = 0.0,
+          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(a, "axpby.a")
+    if out is None:
+        out = torch.empty_like(a)
+    _l.check(_l.load().aldm_axpby(a.data_ptr(), _p(b), out.data_ptr(), alpha, beta, a.numel(),
+                                  _stream()), "axpby")
+    return out
+
+
+def reflect_pad_1d(x: torch.Tensor, pad: int) -> torch.Tensor:
+    """[B, T] -> [B, pitch] rows holding the T + 2*pad reflect-padded samples (stft.py:60-64);
+    pitch = round_up(T + 2*pad, 4) so every frame start stays 16-byte aligned."""
+    _chk(x, "reflect_pad.x")
+    B, T = x.shape
+    pitch = (T + 2 * pad + 3) // 4 * 4
+    buf = torch.zeros((B, pitch), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_reflect_pad_1d(x.data_ptr(), buf.data_ptr(), B, T, pad, pitch, _stream()),
+             "reflect_pad_1d")
+    return buf
+
+
+def frames_gemm(sig: torch.Tensor, frames: int, hop: int, pw: Packed) -> torch.Tensor:
+    """STFT as an implicit GEMM (stft.py:67-72): out[b, f, n] = sum_k sig[b, f*hop + k] * W[k, n].
+    Rows of A overlap (pixel pitch = hop < K = n_fft); one batch (grid z) per signal."""
+    _chk(sig, "frames_gemm.sig")
+    B, pitch = sig.shape
+    K = pw.K
+    assert K % 4 == 0 and hop % 4 == 0 and (frames - 1) * hop + K <= pitch
+    out = torch.empty((B, frames, pw.N), device=sig.device, dtype=torch.float32)
+    d = IgemmDesc()
+    d.x1 = sig.data_ptr(); d.C1 = K; d.pix1 = hop; d.B = 1; d.H = 1; d.W = frames
+    d.up_h = d.up_w = 1
+    d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
+    d.OH = 1; d.OW = frames
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = K; d.N = pw.N
+    d.out = out.data_ptr(); d.ldo = pw.N; d.alpha = 1.0
+    d.batch = B; d.stride_x = pitch; d.stride_w = 0; d.stride_o = frames * pw.N
+    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(frames)")
+    return out
+
+
+def mag_phase(spec: torch.Tensor, F: int, ld_mag: int, want_phase: bool = True):
+    _chk(spec, "mag_phase.spec")
+    M = spec.numel() // spec.shape[-1]
+    mag = torch.empty((M, ld_mag), device=spec.device, dtype=torch.float32)
+    phase = torch.empty((M, F), device=spec.device, dtype=torch.float32) if want_phase else None
+    _l.check(_l.load().aldm_mag_phase(spec.data_ptr(), mag.data_ptr(), _p(phase), M, F,
+                                      spec.shape[-1], ld_mag, _stream()), "mag_phase")
+    return mag, phase

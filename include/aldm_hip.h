@@ -1,0 +1,173 @@
+/*
+ * aldm_hip.h — C ABI of libaldm_hip.so, the MI355X (gfx950) kernel library behind the
+ * AudioLDM2 sampling hot path (DDIM/UNet -> VAE decode -> HiFi-GAN, + STFT/mel).
+ *
+ * The reference (haoheliu/AudioLDM2) has NO native code: every "kernel" on this path is an
+ * ATen op reached from Python.  The entry points below are therefore the op inventory of
+ * SURVEY.md §2.3, one C function per fused op; each comment cites the reference call site
+ * (file:line under /root/reference/audioldm2/) whose arithmetic the entry point replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensors), fp32,
+ *     channels-last ("tokens x C": [B, H, W, C] / [B, L, C]); no torch types cross this ABI;
+ *   - `stream` is a hipStream_t passed as void*; nothing here synchronises or allocates;
+ *   - return value: 0 on success, negative on error; aldm_last_error() gives the message
+ *     (thread local).  Host wrappers turn that into a Python RuntimeError, mirroring the
+ *     reference's plain-exception convention (e.g. openaimodel.py:858-860 asserts).
+ *   - all arithmetic is IEEE fp32 (operands and accumulation): contractions run on
+ *     v_mfma_f32_32x32x2_f32, which is bit-identical to an fp32 fmaf chain.
+ */
+#ifndef ALDM_HIP_H
+#define ALDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library / error ------------------------------------------------------------------ */
+int aldm_version(void);              /* ABI version, bumped on any struct change            */
+const char* aldm_last_error(void);   /* message of the last failing call on this thread     */
+
+/* ---- activations usable as prologue (applied to the gathered input) or epilogue -------- */
+enum {
+    ALDM_ACT_NONE = 0,
+    ALDM_ACT_SILU = 1,      /* x*sigmoid(x): util.py:219-221, model.py:33-35                */
+    ALDM_ACT_LRELU = 2,     /* leaky_relu(x, slope): hifigan/models.py:98,151,161           */
+    ALDM_ACT_TANH = 3,      /* hifigan/models.py:163                                        */
+    ALDM_ACT_LOGCLAMP = 4,  /* log(max(x, slope)): audio_processing.py:85-91 (clip 1e-5)    */
+    ALDM_ACT_GELU = 5       /* exact erf GELU: attention.py:44                              */
+};
+
+/* B-operand layouts of aldm_igemm */
+enum {
+    ALDM_B_PACKED = 0, /* weights pre-packed by aldm_pack_weight: [ceil(K/4)][Npad][4]      */
+    ALDM_B_NT = 1      /* row-major activations Bmat[N][ldb] (C = A * Bmat^T)               */
+};
+
+/*
+ * aldm_igemm — the one contraction engine: implicit-GEMM convolution on fp32 MFMA.
+ *   out[m, n] = epi( sum_k A[m, k] * W[k, n] ),  m = (b, oh, ow),  k = (kh, kw, ci)
+ * A is gathered on the fly from one or two channels-last tensors (x1 ++ x2 along C = the
+ * UNet skip concat, openaimodel.py:879), optionally through a virtual nearest-neighbour
+ * upsample (openaimodel.py:133, model.py:54), optionally through a per-(sample, channel)
+ * affine + activation (= GroupNorm apply + SiLU fused into the conv: openaimodel.py:227-231,
+ * model.py:156-158; or leaky_relu for HiFi-GAN).  Zero padding stays zero.
+ * Replaces: nn.Conv2d (openaimodel.py:122,172,230,256,267,572,810; attention.py:439,452;
+ * model.py:49,139,147,195-203,596,650; autoencoder.py:112), nn.Conv1d / ConvTranspose1d
+ * (hifigan/models.py:24-84,114-141), nn.Linear (attention.py:40,54,335-342;
+ * openaimodel.py:244-250,537-541), F.conv1d DFT basis (stft.py:67-72), torch.bmm
+ * (model.py:219,226), torch.matmul mel basis (stft.py:174).
+ */
+typedef struct aldm_igemm_desc {
+    /* A operand: gathered input */
+    const float* x1;       /* [B, H, W, C1] channels-last                                   */
+    const float* x2;       /* optional second tensor, concatenated after x1 along C         */
+    int32_t C1, C2;        /* channels of x1 / x2 (C2 = 0 when x2 == NULL); multiples of 4  */
+    int32_t pix1, pix2;    /* element pitch between consecutive pixels (0 => C1 / C2)       */
+    int32_t B, H, W;       /* stored input extent                                           */
+    int32_t up_h, up_w;    /* virtual nearest upsample factors (1 = none)                   */
+    int32_t KH, KW, SH, SW, PH, PW, DH, DW;
+    int32_t OH, OW;        /* output extent; M = B*OH*OW                                    */
+    /* prologue on A */
+    const float* pre_scale; /* [B, C1+C2] or NULL: a = a*scale + shift                      */
+    const float* pre_shift;
+    int32_t pre_act;        /* ALDM_ACT_* applied after the affine                          */
+    float pre_slope;
+    /* B operand */
+    const float* w;
+    int32_t b_mode;        /* ALDM_B_PACKED / ALDM_B_NT                                     */
+    int32_t ldb;           /* NT: row pitch of Bmat; PACKED: Npad                           */
+    int32_t K, N;          /* K = KH*KW*(C1+C2) (multiple of 4), N = output channels        */
+    /* epilogue: v = acc + bias[n] + rowbias[b, n]; v = act(v); v = alpha*v + res[m, n];
+       out = accumulate ? out + v : v                                                        */
+    const float* bias;     /* [N] or NULL                                                   */
+    const float* rowbias;  /* [B, N] or NULL (timestep-embedding add, openaimodel.py:298)   */
+    const float* res;      /* [Mout, ldo] or NULL (residual)                                */
+    float* out;            /* [Mout, ldo]                                                   */
+    int32_t ldo;           /* output row pitch in elements (>= N)                           */
+    int32_t act;           /* ALDM_ACT_* epilogue                                           */
+    float act_slope;
+    float alpha;
+    int32_t accumulate;
+    /* output row remap (polyphase ConvTranspose1d, hifigan/models.py:127-134): when
+       out_mul > 0 the GEMM row (b, q) is stored at row b*out_len + q*out_mul + out_off and
+       dropped when that position falls outside [0, out_len).  Requires OH == 1.            */
+    int32_t out_mul, out_off, out_len;
+    /* batched GEMM: blockIdx.z = batch; element strides added per batch (0 = shared)       */
+    int32_t batch;
+    int64_t stride_x, stride_w, stride_o;
+} aldm_igemm_desc;
+
+int aldm_igemm(const aldm_igemm_desc* d, void* stream);
+
+/* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
+ *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1
+ *   transposed=1: ConvTranspose1d layout [Cin, N, KW]; phase/stride select the polyphase
+ *   taps kw = phase + j*stride (j = 0..T-1, T = ceil(KWfull/stride)), stored flipped so the
+ *   phase runs as an ordinary conv with PW = T-1.
+ * dst has ceil(K/4) * Npad * 4 floats, Npad = round_up(N, 32), K = KH*KWeff*Cin.           */
+int aldm_pack_weight(const float* src, float* dst, int N, int Cin, int KH, int KW,
+                     int transposed, int phase, int stride, void* stream);
+/* [K, N] row-major activations -> packed [ceil(K/4)][Npad][4] (P*V of the VAE attention)   */
+int aldm_pack_kn(const float* src, float* dst, int K, int N, int lds, int batch,
+                 int64_t stride_src, int64_t stride_dst, void* stream);
+
+/* ---- normalisation -------------------------------------------------------------------- */
+/* GroupNorm statistics over channels-last x = x1 ++ x2 -> per-(b, c) scale/shift such that
+ * GroupNorm(x)[b, p, c] = x*scale[b, c] + shift[b, c]  (scale = rstd*gamma,
+ * shift = beta - mean*rstd*gamma).  util.py:224-241 (eps 1e-5), attention.py:75-78 and
+ * model.py:38-41 (eps 1e-6).  ws: >= B*chunks*G*2 floats scratch (see aldm_gn_ws_floats). */
+int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1, int C2,
+                         int G, float eps, const float* gamma, const float* beta,
+                         float* scale, float* shift, float* ws, void* stream);
+int64_t aldm_gn_ws_floats(int B, int P, int C, int G);
+/* LayerNorm over the last dim of [M, C] (attention.py:393-395), eps 1e-5                   */
+int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
+                   const float* beta, float eps, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------ */
+/* Multi-head attention, head dim 32, flash-style online softmax on fp32 MFMA:
+ *   out[b, i, h*32:(h+1)*32] = softmax_j(scale * q_i.k_j  [masked -> -FLT_MAX]) @ v
+ * attention.py:343-367.  q/k/v/out are [B, L, *] with independent row pitches so a fused
+ * QKV projection buffer can be consumed in place.  mask: [B, Lk] floats (1 = keep) or NULL
+ * (attention.py:357-361: masked scores are set to -finfo.max, NOT -inf).                   */
+int aldm_attention_d32(const float* q, const float* k, const float* v, float* out,
+                       int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                       const float* mask, float scale, void* stream);
+/* row softmax with pre-scale: y = softmax(scale * x) over the last dim of [M, N]
+ * (model.py:220-221)                                                                        */
+int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale, void* stream);
+
+/* ---- elementwise ---------------------------------------------------------------------- */
+/* GEGLU gate: y[m, c] = x[m, c] * gelu_erf(x[m, C + c]), x: [M, 2C] (attention.py:42-44)   */
+int aldm_geglu(const float* x, float* y, int64_t M, int C, void* stream);
+/* sinusoidal timestep embedding [cos | sin], util.py:172-196; t: [B] floats               */
+int aldm_timestep_embedding(const float* t, float* out, int B, int dim, float max_period,
+                            void* stream);
+/* NCHW <-> NHWC (the reference's rearrange at attention.py:462,465 disappears; only the
+ * 8/16-channel latent crosses layouts at the UNet boundary). rep: write `rep` copies.     */
+int aldm_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int rep, void* stream);
+int aldm_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stream);
+/* Fused classifier-free guidance + DDIM step (ddim.py:298-355).  eps holds [e_uncond ; e_cond]
+ * ([2, n] when cfg != 0 path is used, else [1, n]); coef (device) = {sqrt(1-a_t), sqrt(a_t),
+ * sqrt(1-a_prev-sigma^2), sqrt(a_prev), sigma_t, guidance_scale, use_cfg, 0}.
+ *   e = e_u + s*(e_c - e_u); pred_x0 = (x - c0*e)/c1; x_prev = c3*pred_x0 + c2*e + c4*noise  */
+int aldm_ddim_step(const float* x, const float* eps, const float* noise, const float* coef,
+                   float* x_prev, float* pred_x0, int64_t n, void* stream);
+/* generic y = alpha*a + beta*b (b may be NULL) */
+int aldm_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n,
+               void* stream);
+/* reflect padding of [B, T] by `pad` on both sides into rows of pitch ld_out (stft.py:60-64) */
+int aldm_reflect_pad_1d(const float* x, float* y, int B, int T, int pad, int ld_out,
+                        void* stream);
+/* STFT post: spec [M, ld_spec] = [re(0..F-1) | im(0..F-1)] -> mag [M, ld_mag] (zero padded to
+ * ld_mag), phase [M, F] (atan2(im, re)) (stft.py:74-79)                                     */
+int aldm_mag_phase(const float* spec, float* mag, float* phase, int64_t M, int F, int ld_spec,
+                   int ld_mag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALDM_HIP_H */
