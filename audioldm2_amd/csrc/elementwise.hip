@@ -143,9 +143,34 @@ __global__ void mag_phase_kernel(const float* __restrict__ spec, float* __restri
     }
 }
 
+// out[m] = sqrt(sum_f x[m, f]^2): one wave64 per row (torch.norm(magnitudes, dim=1), stft.py:176)
+__global__ __launch_bounds__(256) void row_l2norm_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ out, int64_t M, int F,
+                                                         int ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) {
+        const float v = x[row * ld + f];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = sqrtf(s);
+}
+
 }  // namespace aldm
 
 using namespace aldm;
+
+extern "C" int aldm_row_l2norm(const float* x, float* out, int64_t M, int F, int ld, void* stream) {
+    ALDM_CHECK(x && out && M > 0 && F > 0 && ld >= F, "aldm_row_l2norm: bad args");
+    hipLaunchKernelGGL(row_l2norm_kernel, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, M, F, ld);
+    ALDM_LAUNCH_CHECK("aldm_row_l2norm");
+    return 0;
+}
 
 extern "C" int aldm_geglu(const float* x, float* y, int64_t M, int C, void* stream) {
     ALDM_CHECK(x && y && M > 0 && C > 0 && C % 4 == 0, "aldm_geglu: bad args (C=%d)", C);

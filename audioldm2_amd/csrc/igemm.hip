@@ -238,9 +238,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
                 if (d.bias) v += d.bias[n];
                 if (d.rowbias) v += d.rowbias[(int64_t)b * d.N + n];
                 v = act_apply(v, d.act, d.act_slope);
-                v *= d.alpha;
                 const int64_t o = orow * d.ldo + n;
                 if (resp) v += resp[o];
+                v *= d.alpha;
                 if (d.accumulate) v += outp[o];
                 outp[o] = v;
             }

@@ -1,0 +1,232 @@
+"""DDIM sampler on MI355X: drop-in for `audioldm2.latent_diffusion.models.ddim.DDIMSampler`
+(models/ddim.py:15-355).  Same constructor / `sample()` / `ddim_sampling()` / `p_sample_ddim()`
+signatures and return values; constructed by name in `LatentDiffusion.sample_log` (ddpm.py:1437), so a
+reference user rebinds `ddpm.DDIMSampler = audioldm2_amd.ddim.DDIMSampler`.
+
+Differences that matter on MI355X:
+  * classifier-free guidance runs as ONE UNet pass over [uncond ; cond] (2B samples) when the model
+    exposes `apply_model_cfg` (the reference runs two sequential passes, ddim.py:293-296);
+  * CFG combine + x0 prediction + x_{t-1} update is one fused kernel (ops.ddim_step);
+  * the per-step launch sequence (~1000 kernels) is captured once into a HIP graph and replayed;
+    timestep, DDIM coefficients and noise are device-side inputs of the graph;
+  * RNG contract: x_T and the per-step noise are drawn from the HOST CPU
+    generator in the reference's order and shapes (ddim.py:191,351 via util.py:289-294), uploaded
+    once — results match the CPU reference on the same seed.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    """util.py:55-75"""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    return ddim_timesteps + 1
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """util.py:78-95 — keeps the reference's mixed float32-tensor / float64-ndarray arithmetic:
+    (1 - alphas) is a float32 tensor op, the rest float64."""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return torch.as_tensor(np.asarray(sigmas, dtype=np.float64)), alphas, alphas_prev
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", device=torch.device("cuda"), **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.device = device
+        self.use_graph = os.environ.get("ALDM_NO_GRAPH", "0") != "1"
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        """ddim.py:33-91 (host side, float tables only)."""
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        alphas_cumprod = self.model.alphas_cumprod.detach().float().cpu()
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        self.alphas_cumprod = alphas_cumprod
+        self.sqrt_alphas_cumprod = torch.sqrt(alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - alphas_cumprod)
+        sig, a, a_prev = make_ddim_sampling_parameters(alphas_cumprod, self.ddim_timesteps, ddim_eta, verbose)
+        self.ddim_sigmas = sig
+        self.ddim_alphas = a
+        self.ddim_alphas_prev = a_prev
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1.0 - a.numpy())
+        # per-index coefficient rows with the reference's roundings (ddim.py:330-353): a_t, a_prev,
+        # sigma_t, sqrt(1-a_t) become fp32 via torch.full; the other square roots are fp32 tensor ops.
+        rows = []
+        for i in range(len(self.ddim_timesteps)):
+            a_t = torch.full((1,), float(a[i]))
+            ap = torch.full((1,), float(a_prev[i]))
+            sg = torch.full((1,), float(sig[i]))
+            som = torch.full((1,), float(self.ddim_sqrt_one_minus_alphas[i]))
+            rows.append(torch.cat([som, a_t.sqrt(), (1.0 - ap - sg ** 2).sqrt(), ap.sqrt(), sg]))
+        self.ddim_coef = torch.stack(rows)  # [S, 5] fp32 (host)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0.0, mask=None, x0=None, temperature=1.0,
+               noise_dropout=0.0, score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None,
+               log_every_t=100, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               dynamic_threshold=None, ucg_schedule=None, **kwargs):
+        """ddim.py:94-163"""
+        if quantize_x0 or score_corrector is not None or dynamic_threshold is not None \
+                or noise_dropout != 0.0 or ucg_schedule is not None:
+            raise NotImplementedError("DDIMSampler(HIP): option not used by the AudioLDM2 pipeline")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  mask=mask, x0=x0, temperature=temperature, x_T=x_T,
+                                  log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning)
+
+    # ------------------------------------------------------------------------------------------
+    def _draw_noise(self, shape, steps, x_T, with_mask):
+        """Replays the reference's host RNG order: x_T, then per step [q_sample noise (inpainting
+        only, ddim.py:228 / ddpm.py:430-436)], step noise (ddim.py:351)."""
+        img = torch.randn(shape) if x_T is None else x_T
+        step_noise, q_noise = [], []
+        for _ in range(steps):
+            if with_mask:
+                q_noise.append(torch.randn(shape))
+            step_noise.append(torch.randn(shape))
+        return img, torch.stack(step_noise), (torch.stack(q_noise) if with_mask else None)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None,
+                      timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None,
+                      log_every_t=100, temperature=1.0, noise_dropout=0.0, score_corrector=None,
+                      corrector_kwargs=None, unconditional_guidance_scale=1.0,
+                      unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None):
+        """ddim.py:166-262"""
+        if ddim_use_original_steps or timesteps is not None:
+            raise NotImplementedError("DDIMSampler(HIP): only the DDIM sub-sequence path is implemented")
+        dev = torch.device("cuda")
+        b = shape[0]
+        ts = self.ddim_timesteps
+        total_steps = ts.shape[0]
+        time_range = np.flip(ts)
+        use_cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
+
+        x_host = None if x_T is None else x_T.detach().float().cpu()
+        img_h, noise_h, qnoise_h = self._draw_noise(tuple(shape), total_steps, x_host, mask is not None)
+        img = img_h.to(dev).contiguous()
+        noise = (noise_h * temperature).to(dev) if temperature != 1.0 else noise_h.to(dev)
+        # device tables in loop order (i = 0 is the noisiest step, index = total_steps - 1)
+        order = [total_steps - i - 1 for i in range(total_steps)]
+        coef = torch.zeros(total_steps, 8)
+        coef[:, :5] = self.ddim_coef[order]
+        coef[:, 5] = float(unconditional_guidance_scale)
+        coef[:, 6] = 1.0 if use_cfg else 0.0
+        coef = coef.to(dev)
+        nrep = 2 if use_cfg else 1
+        t_tab = torch.from_numpy(np.ascontiguousarray(time_range)).float()[:, None].repeat(1, nrep * b).to(dev)
+
+        if mask is not None:
+            assert x0 is not None
+            mask_d = mask.float().to(dev).expand(shape).contiguous()
+            x0_d = x0.float().to(dev).contiguous()
+            qn = qnoise_h.to(dev)
+            sa = self.sqrt_alphas_cumprod[torch.from_numpy(np.ascontiguousarray(time_range - 0))].to(dev)
+            so = self.sqrt_one_minus_alphas_cumprod[torch.from_numpy(np.ascontiguousarray(time_range - 0))].to(dev)
+
+        # static buffers = the graph's inputs
+        x_cur = img.clone()
+        x_next = torch.empty_like(x_cur)
+        pred_x0 = torch.empty_like(x_cur)
+        t_cur = t_tab[0].clone()
+        coef_cur = coef[0].clone()
+        noise_cur = noise[0].clone()
+
+        cfg_fused = use_cfg and hasattr(self.model, "apply_model_cfg")
+
+        def step():
+            if use_cfg:
+                if cfg_fused:
+                    eps = self.model.apply_model_cfg(x_cur, t_cur, cond, unconditional_conditioning)
+                else:
+                    tl = t_cur[:b].long()
+                    e_u = self.model.apply_model(x_cur, tl, unconditional_conditioning)
+                    e_c = self.model.apply_model(x_cur, tl, cond)
+                    eps = torch.stack([e_u, e_c]).contiguous()
+            else:
+                eps = self.model.apply_model(x_cur, t_cur[:b].long(), cond).contiguous()
+            ops.ddim_step(x_cur, eps, noise_cur, coef_cur, x_next, pred_x0)
+            x_cur.copy_(x_next)
+
+        graph = None
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        for i, step_t in enumerate(time_range):
+            index = total_steps - i - 1
+            t_cur.copy_(t_tab[i])
+            coef_cur.copy_(coef[i])
+            noise_cur.copy_(noise[i])
+            if mask is not None:
+                # img = q_sample(x0, ts)*mask + (1-mask)*img   (ddim.py:226-231, ddpm.py:430-436)
+                img_orig = sa[i] * x0_d + so[i] * qn[i]
+                x_cur.copy_(img_orig * mask_d + (1.0 - mask_d) * x_cur)
+            if self.use_graph and i >= 1:
+                if graph is None:
+                    graph = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(graph):
+                        step()
+                graph.replay()
+            else:
+                step()  # first step runs eagerly: packs weights, warms the allocator
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates["x_inter"].append(x_cur.clone())
+                intermediates["pred_x0"].append(pred_x0.clone())
+        return x_cur.clone(), intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False,
+                      quantize_denoised=False, temperature=1.0, noise_dropout=0.0, score_corrector=None,
+                      corrector_kwargs=None, unconditional_guidance_scale=1.0,
+                      unconditional_conditioning=None, dynamic_threshold=None):
+        """ddim.py:265-355 — single step with the reference's signature (noise from the host CPU
+        generator, like `noise_like` does on a CPU reference run)."""
+        b = x.shape[0]
+        use_cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
+        if use_cfg:
+            if hasattr(self.model, "apply_model_cfg"):
+                eps = self.model.apply_model_cfg(x, t.float().repeat(2), c, unconditional_conditioning)
+            else:
+                eps = torch.stack([self.model.apply_model(x, t, unconditional_conditioning),
+                                   self.model.apply_model(x, t, c)]).contiguous()
+        else:
+            eps = self.model.apply_model(x, t, c).contiguous()
+        coef = torch.zeros(8)
+        coef[:5] = self.ddim_coef[index]
+        coef[5] = float(unconditional_guidance_scale)
+        coef[6] = 1.0 if use_cfg else 0.0
+        if repeat_noise:
+            noise = torch.randn((1, *x.shape[1:])).repeat(b, 1, 1, 1)
+        else:
+            noise = torch.randn(x.shape)
+        noise = (noise * temperature).to(x.device)
+        x_prev, pred_x0 = ops.ddim_step(x.float().contiguous(), eps, noise.contiguous(), coef.to(x.device))
+        return x_prev, pred_x0

@@ -76,6 +76,7 @@ _SIGS = {
                                       C.c_void_p]),
     "aldm_mag_phase": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p]),
+    "aldm_row_l2norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 
 # every symbol include/aldm_hip.h declares (checked by tests/test_abi.py without a GPU)

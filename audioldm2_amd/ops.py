@@ -152,35 +152,42 @@ def linear(x: torch.Tensor, pw: Packed, **kw) -> torch.Tensor:
     return y.view(*shp[:-1], pw.N)
 
 
+def _view3(t: torch.Tensor, name: str):
+    """[Z, R, D] fp32 CUDA view with unit inner stride (a column slice of a wider buffer is fine)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1):
+        raise RuntimeError(f"{name}: need a [Z, R, D] fp32 CUDA view with unit inner stride")
+    return t.data_ptr(), t.stride(0), t.stride(1)
+
+
 def gemm_nt(a: torch.Tensor, bmat: torch.Tensor, *, alpha: float = 1.0,
             out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Batched C[z] = alpha * A[z] @ Bmat[z]^T with A [Z, M, K], Bmat [Z, N, K] (activation x
+    """Batched C[z] = alpha * A[z] @ Bmat[z]^T with A [Z, M, K], Bmat [Z, N, K] views (activation x
     activation product: Q K^T of the VAE mid attention, model.py:219)."""
-    _chk(a, "gemm_nt.a"); _chk(bmat, "gemm_nt.b")
+    ap, sa, lda = _view3(a, "gemm_nt.a")
+    bp, sb, ldb = _view3(bmat, "gemm_nt.b")
     Z, M, K = a.shape
     Zb, N, Kb = bmat.shape
     assert Z == Zb and K == Kb and K % 4 == 0
     if out is None:
         out = torch.empty((Z, M, N), device=a.device, dtype=torch.float32)
     d = IgemmDesc()
-    d.x1 = a.data_ptr(); d.C1 = K; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
+    d.x1 = ap; d.C1 = K; d.pix1 = lda; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
-    d.w = bmat.data_ptr(); d.b_mode = B_NT; d.ldb = K; d.K = K; d.N = N
+    d.w = bp; d.b_mode = B_NT; d.ldb = ldb; d.K = K; d.N = N
     d.out = out.data_ptr(); d.ldo = N; d.alpha = alpha
-    d.batch = Z; d.stride_x = M * K; d.stride_w = N * K; d.stride_o = M * N
+    d.batch = Z; d.stride_x = sa; d.stride_w = sb; d.stride_o = M * N
     _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(nt)")
     return out
 
 
 def pack_kn(src: torch.Tensor) -> torch.Tensor:
-    """[Z, K, N] row-major activations -> packed B operand [Z][ceil(K/4)][Npad][4]."""
-    _chk(src, "pack_kn.src")
+    """[Z, K, N] activations (row pitch may exceed N) -> packed B operand [Z][ceil(K/4)][Npad][4]."""
+    sp, ss, lds = _view3(src, "pack_kn.src")
     Z, K, N = src.shape
     per = ((K + 3) // 4) * _npad(N) * 4
     dst = torch.empty((Z, per), device=src.device, dtype=torch.float32)
-    _l.check(_l.load().aldm_pack_kn(src.data_ptr(), dst.data_ptr(), K, N, N, Z, K * N, per, _stream()),
-             "pack_kn")
+    _l.check(_l.load().aldm_pack_kn(sp, dst.data_ptr(), K, N, lds, Z, ss, per, _stream()), "pack_kn")
     return dst
 
 
@@ -373,3 +380,12 @@ def mag_phase(spec: torch.Tensor, F: int, ld_mag: int, want_phase: bool = True):
     _l.check(_l.load().aldm_mag_phase(spec.data_ptr(), mag.data_ptr(), _p(phase), M, F,
                                       spec.shape[-1], ld_mag, _stream()), "mag_phase")
     return mag, phase
+
+
+def row_l2norm(x: torch.Tensor, F: int) -> torch.Tensor:
+    """x: [M, ld] -> [M] with out[m] = ||x[m, :F]||_2."""
+    _chk(x, "row_l2norm.x")
+    M, ld = x.shape
+    out = torch.empty((M,), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_row_l2norm(x.data_ptr(), out.data_ptr(), M, F, ld, _stream()), "row_l2norm")
+    return out

@@ -1,0 +1,405 @@
+"""UNetModel on MI355X: drop-in for the reference's
+`audioldm2.latent_diffusion.modules.diffusionmodules.openaimodel.UNetModel` (openaimodel.py:441-885).
+
+Same constructor kwargs, same state-dict keys/shapes (so `load_state_dict(strict=True)` of a reference
+checkpoint's `model.diffusion_model.*` entries works), same call signature
+`forward(x, timesteps, y=None, context_list=None, context_attn_mask_list=None)` with NCHW fp32 I/O —
+usable through the reference's `unet_config.target` plugin seam (utils.py:329-344, ddpm.py:1803).
+
+What is different is everything underneath: the nn.Conv2d/Linear/GroupNorm children are only
+parameter holders; forward() runs channels-last on the HIP kernel library (audioldm2_amd.ops):
+  * GroupNorm+SiLU are fused into the consuming conv's operand gather (stats kernel + igemm prologue),
+  * skip-concat, nearest-upsample, timestep-embedding add and residual add are igemm pro/epilogues,
+  * tokens stay [B, H*W, C] so SpatialTransformer needs no rearrange; q/k/v are one fused GEMM,
+  * attention is a flash-style fp32 MFMA kernel (no score matrix in HBM).
+There is no PyTorch fallback: without libaldm_hip.so forward() raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_SILU
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders (names mirror the reference so checkpoints load unchanged)
+# ------------------------------------------------------------------------------------------------
+class ResBlock(nn.Module):
+    """openaimodel.py:188-300 (use_scale_shift_norm=False, no resblock_updown in AudioLDM2 configs)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(),
+                                       nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+        self._pk = None
+
+    def _prepare(self):
+        if self._pk is None:
+            c1, c2 = self.in_layers[2], self.out_layers[3]
+            self._pk = dict(
+                gn1=(self.in_layers[0].weight.detach().float().cuda().contiguous(),
+                     self.in_layers[0].bias.detach().float().cuda().contiguous()),
+                gn2=(self.out_layers[0].weight.detach().float().cuda().contiguous(),
+                     self.out_layers[0].bias.detach().float().cuda().contiguous()),
+                conv1=ops.pack_conv(c1.weight, c1.bias),
+                conv2=ops.pack_conv(c2.weight, c2.bias),
+                emb=ops.pack_conv(self.emb_layers[1].weight, self.emb_layers[1].bias),
+                skip=None if isinstance(self.skip_connection, nn.Identity)
+                else ops.pack_conv(self.skip_connection.weight, self.skip_connection.bias),
+            )
+        return self._pk
+
+    def run(self, x, emb, x2=None):
+        """x (++ x2 along C): channels-last [B, H, W, C]; emb: [B, emb_channels]."""
+        pk = self._prepare()
+        sc, sh = ops.gn_stats(x, *pk["gn1"], groups=32, eps=1e-5, x2=x2)
+        e = ops.linear(emb, pk["emb"], pre_act=ACT_SILU)
+        h = ops.conv(x, pk["conv1"], x2=x2, pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU, rowbias=e)
+        sc2, sh2 = ops.gn_stats(h, *pk["gn2"], groups=32, eps=1e-5)
+        if pk["skip"] is None:
+            assert x2 is None
+            skip = x
+        else:
+            skip = ops.conv(x, pk["skip"], x2=x2)
+        return ops.conv(h, pk["conv2"], pad=(1, 1), pre=(sc2, sh2), pre_act=ACT_SILU, res=skip)
+
+
+class Downsample(nn.Module):
+    """openaimodel.py:150-186 (conv_resample=True): conv3x3 stride 2."""
+
+    def __init__(self, channels, use_conv=True, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert use_conv and dims == 2
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.op = nn.Conv2d(channels, self.out_channels, 3, stride=2, padding=padding)
+        self._pk = None
+
+    def run(self, x):
+        if self._pk is None:
+            self._pk = ops.pack_conv(self.op.weight, self.op.bias)
+        return ops.conv(x, self._pk, stride=(2, 2), pad=(1, 1))
+
+
+class Upsample(nn.Module):
+    """openaimodel.py:106-136: nearest x2 then conv3x3 — fused into one gather."""
+
+    def __init__(self, channels, use_conv=True, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert use_conv and dims == 2
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.conv = nn.Conv2d(channels, self.out_channels, 3, padding=padding)
+        self._pk = None
+
+    def run(self, x):
+        if self._pk is None:
+            self._pk = ops.pack_conv(self.conv.weight, self.conv.bias)
+        return ops.conv(x, self._pk, pad=(1, 1), up=(2, 2))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    """attention.py:47-63 (glu=True, mult=4)"""
+
+    def __init__(self, dim, mult=4, dropout=0.0):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(dropout), nn.Linear(dim * mult, dim))
+
+
+class CrossAttention(nn.Module):
+    """attention.py:325-367 parameter holder."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        context_dim = query_dim if context_dim is None else context_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(dropout))
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:370-410"""
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None):
+        super().__init__()
+        assert d_head == 32, "the HIP attention kernel is specialised for head dim 32 (all AudioLDM2 configs)"
+        self.attn1 = CrossAttention(dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout)
+        self.attn2 = CrossAttention(dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.heads = n_heads
+        self.dim = dim
+        self._pk = None
+
+    def _prepare(self):
+        if self._pk is None:
+            f = lambda t: t.detach().float().cuda().contiguous()
+            a1, a2 = self.attn1, self.attn2
+            self._pk = dict(
+                ln=[(f(n.weight), f(n.bias)) for n in (self.norm1, self.norm2, self.norm3)],
+                qkv1=ops.pack_conv(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0)),
+                out1=ops.pack_conv(a1.to_out[0].weight, a1.to_out[0].bias),
+                # attn2 used as self-attention when no context is routed to this transformer
+                qkv2=ops.pack_conv(torch.cat([a2.to_q.weight, a2.to_k.weight, a2.to_v.weight], 0))
+                if a2.to_k.weight.shape[1] == self.dim else None,
+                q2=ops.pack_conv(a2.to_q.weight),
+                kv2=ops.pack_conv(torch.cat([a2.to_k.weight, a2.to_v.weight], 0)),
+                out2=ops.pack_conv(a2.to_out[0].weight, a2.to_out[0].bias),
+                ff1=ops.pack_conv(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias),
+                ff2=ops.pack_conv(self.ff.net[2].weight, self.ff.net[2].bias),
+            )
+        return self._pk
+
+    def run(self, h, context=None, mask=None):
+        """h: [B, L, C] tokens.  attention.py:406-410 (mask is ignored when context is None: :400-404)."""
+        pk = self._prepare()
+        C = self.dim
+        n = ops.layernorm(h, *pk["ln"][0])
+        qkv = ops.linear(n, pk["qkv1"])
+        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
+        h = ops.linear(a, pk["out1"], res=h)
+        n = ops.layernorm(h, *pk["ln"][1])
+        if context is None:
+            if pk["qkv2"] is None:
+                raise RuntimeError("attn2 was built with a context_dim but no context was provided")
+            qkv = ops.linear(n, pk["qkv2"])
+            a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
+        else:
+            q = ops.linear(n, pk["q2"])
+            kv = ops.linear(context, pk["kv2"])
+            a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads, mask=mask)
+        h = ops.linear(a, pk["out2"], res=h)
+        n = ops.layernorm(h, *pk["ln"][2])
+        g = ops.geglu(ops.linear(n, pk["ff1"]))
+        return ops.linear(g, pk["ff2"], res=h)
+
+
+class SpatialTransformer(nn.Module):
+    """attention.py:413-467"""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None):
+        super().__init__()
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = nn.GroupNorm(32, in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim)
+             for _ in range(depth)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+        self._pk = None
+
+    def run(self, x, context=None, mask=None):
+        if self._pk is None:
+            self._pk = dict(gn=(self.norm.weight.detach().float().cuda().contiguous(),
+                                self.norm.bias.detach().float().cuda().contiguous()),
+                            pin=ops.pack_conv(self.proj_in.weight, self.proj_in.bias),
+                            pout=ops.pack_conv(self.proj_out.weight, self.proj_out.bias))
+        pk = self._pk
+        B, H, W, C = x.shape
+        sc, sh = ops.gn_stats(x, *pk["gn"], groups=32, eps=1e-6)
+        h = ops.conv(x, pk["pin"], pre=(sc, sh)).view(B, H * W, -1)
+        for blk in self.transformer_blocks:
+            h = blk.run(h, context, mask)
+        return ops.conv(h.view(B, H, W, -1), pk["pout"], res=x)
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    """openaimodel.py:75-103: routes emb to ResBlocks and (context, mask) to SpatialTransformers; the
+    first transformer of a block never gets a context, transformers beyond the list get None."""
+
+    def run(self, x, emb, context_list, mask_list, x2=None):
+        ctxs = [None] + list(context_list)
+        masks = [None] + list(mask_list)
+        st_id = 0
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x = layer.run(x, emb, x2)
+                x2 = None
+            elif isinstance(layer, SpatialTransformer):
+                if st_id >= len(ctxs):
+                    c, m = None, None
+                else:
+                    c, m = ctxs[st_id], masks[st_id]
+                x = layer.run(x, c, m)
+                st_id += 1
+            elif isinstance(layer, (Downsample, Upsample)):
+                x = layer.run(x)
+            elif isinstance(layer, _ConvIn):
+                x = layer.run(x)
+            else:  # pragma: no cover
+                raise RuntimeError(f"unexpected layer {type(layer)}")
+        assert x2 is None, "skip tensor was not consumed by a ResBlock"
+        return x
+
+
+class _ConvIn(nn.Conv2d):
+    """input_blocks.0.0: plain conv3x3 (openaimodel.py:570-574) — subclass only to carry run()."""
+
+    _pk = None
+
+    def run(self, x):
+        if self._pk is None:
+            self._pk = ops.pack_conv(self.weight, self.bias)
+        return ops.conv(x, self._pk, pad=(1, 1))
+
+
+# ------------------------------------------------------------------------------------------------
+class UNetModel(nn.Module):
+    """Constructor kwargs as openaimodel.py:469-497; see module docstring."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 extra_sa_layer=True, num_classes=None, extra_film_condition_dim=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False, use_spatial_transformer=True, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        if dims != 2 or use_scale_shift_norm or resblock_updown or not use_spatial_transformer \
+                or n_embed is not None or num_classes is not None or use_fp16 or not conv_resample:
+            raise NotImplementedError("UNetModel(HIP): only the option set used by the AudioLDM2 configs "
+                                      "(utils.py:329-343) is implemented")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        assert num_heads != -1 or num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.channel_mult = channel_mult
+        self.extra_film_condition_dim = extra_film_condition_dim
+        self.use_extra_film_by_concat = extra_film_condition_dim is not None
+        self.dtype = torch.float32
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        if self.use_extra_film_by_concat:
+            self.film_emb = nn.Linear(extra_film_condition_dim, ted)
+        if context_dim is not None and not isinstance(context_dim, (list, tuple)):
+            context_dim = [context_dim]
+        elif context_dim is None:
+            context_dim = [None]
+        context_dim = list(context_dim)
+        emb_ch = ted * 2 if self.use_extra_film_by_concat else ted
+
+        def transformers(ch):
+            if num_head_channels == -1:
+                heads, dim_head = num_heads, ch // num_heads
+            else:
+                heads, dim_head = ch // num_head_channels, num_head_channels
+            out = []
+            if extra_sa_layer:
+                out.append(SpatialTransformer(ch, heads, dim_head, depth=transformer_depth, context_dim=None))
+            for cd in context_dim:
+                out.append(SpatialTransformer(ch, heads, dim_head, depth=transformer_depth, context_dim=cd))
+            return out
+
+        self.input_blocks = nn.ModuleList(
+            [TimestepEmbedSequential(_ConvIn(in_channels, model_channels, 3, padding=1))])
+        chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, emb_ch, dropout, out_channels=mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers += transformers(ch)
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, True, out_channels=ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, emb_ch, dropout), *transformers(ch), ResBlock(ch, emb_ch, dropout))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [ResBlock(ch + ich, emb_ch, dropout, out_channels=model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers += transformers(ch)
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, True, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(),
+                                 nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        self._pk = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    # -- packed-weight cache ---------------------------------------------------------------------
+    def invalidate_packed(self):
+        """Drop every re-laid-out weight copy (call after mutating parameters)."""
+        for m in self.modules():
+            if hasattr(m, "_pk"):
+                m._pk = None
+
+    def _prepare(self):
+        if self._pk is None:
+            f = lambda t: t.detach().float().cuda().contiguous()
+            self._pk = dict(
+                te0=ops.pack_conv(self.time_embed[0].weight, self.time_embed[0].bias),
+                te2=ops.pack_conv(self.time_embed[2].weight, self.time_embed[2].bias),
+                film=ops.pack_conv(self.film_emb.weight, self.film_emb.bias)
+                if self.use_extra_film_by_concat else None,
+                gn=(f(self.out[0].weight), f(self.out[0].bias)),
+                out=ops.pack_conv(self.out[2].weight, self.out[2].bias),
+            )
+        return self._pk
+
+    # -- forward -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, y=None, context_list=None, context_attn_mask_list=None, **kwargs):
+        """openaimodel.py:837-885.  x: [N, C, H, W] fp32 on the GPU; returns eps [N, C_out, H, W]."""
+        assert (y is not None) == self.use_extra_film_by_concat, \
+            "must specify y if and only if the model is class-conditional or film embedding conditional"
+        if not x.is_cuda:
+            raise RuntimeError("UNetModel(HIP) runs on the MI355X only; there is no CPU path")
+        pk = self._prepare()
+        context_list = [c.float().contiguous() if c is not None else None for c in (context_list or [])]
+        mask_list = list(context_attn_mask_list or [])
+        t_emb = ops.timestep_embedding(timesteps, self.model_channels)
+        emb = ops.linear(ops.linear(t_emb, pk["te0"], act=ACT_SILU), pk["te2"])
+        if self.use_extra_film_by_concat:
+            emb = torch.cat([emb, ops.linear(y.float().contiguous(), pk["film"])], dim=-1).contiguous()
+        h = ops.nchw_to_nhwc(x.float().contiguous())
+        hs = []
+        for module in self.input_blocks:
+            h = module.run(h, emb, context_list, mask_list)
+            hs.append(h)
+        h = self.middle_block.run(h, emb, context_list, mask_list)
+        for module in self.output_blocks:
+            h = module.run(h, emb, context_list, mask_list, x2=hs.pop())
+        sc, sh = ops.gn_stats(h, *pk["gn"], groups=32, eps=1e-5)
+        out = ops.conv(h, pk["out"], pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU)
+        return ops.nhwc_to_nchw(out)

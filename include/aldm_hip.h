@@ -80,8 +80,8 @@ typedef struct aldm_igemm_desc {
     int32_t b_mode;        /* ALDM_B_PACKED / ALDM_B_NT                                     */
     int32_t ldb;           /* NT: row pitch of Bmat; PACKED: Npad                           */
     int32_t K, N;          /* K = KH*KW*(C1+C2) (multiple of 4), N = output channels        */
-    /* epilogue: v = acc + bias[n] + rowbias[b, n]; v = act(v); v = alpha*v + res[m, n];
-       out = accumulate ? out + v : v                                                        */
+    /* epilogue: v = act(acc + bias[n] + rowbias[b, n]); v = alpha*(v + res[m, n]);
+       out = accumulate ? out + v : v   (HiFi-GAN: xs += (resblock_j(x))/num_kernels)        */
     const float* bias;     /* [N] or NULL                                                   */
     const float* rowbias;  /* [B, N] or NULL (timestep-embedding add, openaimodel.py:298)   */
     const float* res;      /* [Mout, ldo] or NULL (residual)                                */
@@ -166,6 +166,10 @@ int aldm_reflect_pad_1d(const float* x, float* y, int B, int T, int pad, int ld_
  * ld_mag), phase [M, F] (atan2(im, re)) (stft.py:74-79)                                     */
 int aldm_mag_phase(const float* spec, float* mag, float* phase, int64_t M, int F, int ld_spec,
                    int ld_mag, void* stream);
+
+/* out[m] = ||x[m, 0:F]||_2 over rows of pitch ld (energy = torch.norm(magnitudes, dim=1),
+ * stft.py:176)                                                                              */
+int aldm_row_l2norm(const float* x, float* out, int64_t M, int F, int ld, void* stream);
 
 #ifdef __cplusplus
 }

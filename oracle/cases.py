@@ -1,0 +1,105 @@
+"""Seeded test cases shared by oracle/make_golden.py (which runs the REAL reference on them) and the
+tests (which run the oracle restatement and the HIP product on them).  TEST INFRA ONLY.
+
+Every input is regenerated from a seed, so fixtures only have to store reference OUTPUTS.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+# --- UNet ----------------------------------------------------------------------------------------
+UNET_TINY = {"image_size": 64, "context_dim": [768, 1024], "in_channels": 8, "out_channels": 8,
+             "model_channels": 128, "attention_resolutions": [2, 1], "num_res_blocks": 1,
+             "channel_mult": [1, 2], "num_head_channels": 32, "use_spatial_transformer": True,
+             "transformer_depth": 1}
+UNET_FULL = {"image_size": 64, "context_dim": [768, 1024], "in_channels": 8, "out_channels": 8,
+             "model_channels": 128, "attention_resolutions": [8, 4, 2], "num_res_blocks": 2,
+             "channel_mult": [1, 2, 3, 5], "num_head_channels": 32, "use_spatial_transformer": True,
+             "transformer_depth": 1}
+# -large-: third (context-free) transformer per location + depth 2 (utils.py:118-120), shrunk
+UNET_LARGE_TINY = dict(UNET_TINY, context_dim=[768, 1024, None], transformer_depth=2)
+# 48k: FiLM conditioning, no cross-attention context (utils.py:526-539), shrunk
+UNET_FILM_TINY = {"image_size": 64, "extra_film_condition_dim": 512, "context_dim": [None], "in_channels": 16,
+                  "out_channels": 16, "model_channels": 128, "attention_resolutions": [2, 1],
+                  "num_res_blocks": 1, "channel_mult": [1, 2], "num_head_channels": 32,
+                  "use_spatial_transformer": True, "transformer_depth": 1}
+
+
+def unet_inputs(cfg: dict, B: int, H: int, W: int, t5_len: int = 12, seed: int = 0):
+    """x, t, context_list, mask_list, y for a UNet config."""
+    g = torch.Generator().manual_seed(1234 + seed)
+    x = torch.randn(B, cfg["in_channels"], H, W, generator=g)
+    t = torch.tensor([801, 6, 996, 301][:B] if B <= 4 else [(37 * i) % 1000 + 1 for i in range(B)])
+    ctxs, masks = [], []
+    for cd in cfg["context_dim"]:
+        if cd is None:
+            continue
+        L = 8 if cd == 768 else t5_len
+        ctxs.append(torch.randn(B, L, cd, generator=g))
+        m = torch.ones(B, L)
+        if cd != 768 and B > 1:
+            m[1::2, -max(1, L // 3):] = 0
+        masks.append(m)
+    y = None
+    if cfg.get("extra_film_condition_dim") is not None:
+        y = torch.randn(B, cfg["extra_film_condition_dim"], generator=g)
+        y = y / y.norm(dim=-1, keepdim=True)
+    return x, t, ctxs, masks, y
+
+
+# --- VAE / vocoder --------------------------------------------------------------------------------
+DDCONFIG_16K = {"double_z": True, "mel_bins": 64, "z_channels": 8, "resolution": 256, "downsample_time": False,
+                "in_channels": 1, "out_ch": 1, "ch": 128, "ch_mult": [1, 2, 4], "num_res_blocks": 2,
+                "attn_resolutions": [], "dropout": 0}
+DDCONFIG_48K = {"double_z": True, "mel_bins": 256, "z_channels": 16, "resolution": 256, "downsample_time": False,
+                "in_channels": 1, "out_ch": 1, "ch": 128, "ch_mult": [1, 2, 4, 8], "num_res_blocks": 2,
+                "attn_resolutions": [], "dropout": 0}
+HIFIGAN_16K = dict(upsample_rates=[5, 4, 2, 2, 2], upsample_kernel_sizes=[16, 16, 8, 4, 4],
+                   upsample_initial_channel=1024, resblock_kernel_sizes=[3, 7, 11],
+                   resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=64, resblock="1")
+HIFIGAN_48K = dict(upsample_rates=[6, 5, 4, 2, 2], upsample_kernel_sizes=[12, 10, 8, 4, 4],
+                   upsample_initial_channel=1536, resblock_kernel_sizes=[3, 7, 11, 15],
+                   resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5], [1, 3, 5]], num_mels=256,
+                   resblock="1")
+
+
+def latent_input(B, C, H, W, seed=0):
+    return torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(77 + seed))
+
+
+def mel_input(B, n_mel, T, seed=0):
+    """log-mel-like values (roughly the range a trained VAE decodes to)."""
+    g = torch.Generator().manual_seed(99 + seed)
+    return torch.randn(B, n_mel, T, generator=g) * 2.0 - 4.0
+
+
+def wave_input(B, T, seed=0):
+    g = torch.Generator().manual_seed(55 + seed)
+    x = 0.5 * (torch.rand(B, T, generator=g) * 2 - 1)
+    tt = torch.arange(T, dtype=torch.float32) / 16000.0
+    x[0] = 0.5 * torch.sin(2 * torch.pi * 440.0 * tt)  # 440 Hz known-answer row
+    return x
+
+
+# --- end-to-end ---------------------------------------------------------------------------------------
+SCALE_FACTOR = 0.75
+E2E_SEED = 42
+
+
+def e2e_cond_config(device: str, t5_len: int = 32):
+    from audioldm2_amd.pipeline import default_audioldm_config
+    cond = copy.deepcopy(default_audioldm_config("audioldm2-full", t5_len)["model"]["params"]["cond_stage_config"])
+    for k in cond:
+        cond[k]["params"]["device"] = device
+    return cond
+
+
+def e2e_batch(B: int):
+    """pipeline.py:112-121 batch layout (all-zero audio features, text tiled B times)."""
+    text = ["a dog barking in the rain"] * B
+    fbank = torch.zeros((B, 1024, 64))
+    return {"text": text, "fname": [t.replace(" ", "_") for t in text], "waveform": torch.zeros((B, 160000)),
+            "stft": torch.zeros((B, 1024, 512)), "log_mel_spec": fbank, "fbank": fbank,
+            "ta_kaldi_fbank": torch.zeros((B, 1024, 128)), "phoneme_idx": torch.zeros((B, 310), dtype=torch.long)}

@@ -1,0 +1,84 @@
+"""Oracle: DDPM noise schedule + DDIM sampler restated on the CPU.  TEST INFRA ONLY.
+
+  make_beta_schedule("linear")      diffusionmodules/util.py:20-31   (float64 linspace of sqrt, squared)
+  DDPM.register_schedule            models/ddpm.py:201-303           (alphas_cumprod -> float32 buffers)
+  make_ddim_timesteps("uniform")    util.py:55-75                    (range(0, T, T//S) + 1)
+  make_ddim_sampling_parameters     util.py:78-95                    (sigma_t in float64)
+  DDIMSampler.make_schedule         models/ddim.py:33-91
+  DDIMSampler.ddim_sampling         models/ddim.py:166-262
+  DDIMSampler.p_sample_ddim         models/ddim.py:265-355           (CFG + eps-parameterised update)
+RNG contract: x_T = randn(shape) then one randn(shape) per step, all from the
+global CPU generator in that order — callers seed with torch.manual_seed(seed) beforehand.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+
+def make_schedule_buffers(timesteps: int = 1000, linear_start: float = 0.0015, linear_end: float = 0.0195):
+    """ddpm.py:201-303 (schedule 'linear').  Returns float32 torch buffers like the reference."""
+    betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2).numpy()
+    alphas = 1.0 - betas
+    alphas_cumprod = np.cumprod(alphas, axis=0)
+    alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+    return {"betas": f32(betas), "alphas_cumprod": f32(alphas_cumprod),
+            "alphas_cumprod_prev": f32(alphas_cumprod_prev)}
+
+
+def ddim_tables(alphas_cumprod: torch.Tensor, S: int, eta: float, T: int = 1000):
+    """ddim.py:33-91 + util.py:55-95.  Returns (timesteps[S] int, coef[S, 5] float32) where coef row i
+    (DDIM index i) = [sqrt(1-a_t), sqrt(a_t), sqrt(1-a_prev-sigma^2), sqrt(a_prev), sigma] computed with
+    the reference's dtypes: a_t, a_prev, sigma, sqrt(1-a_t) are rounded to fp32 by torch.full
+    (ddim.py:330-335) and the remaining square roots are fp32 tensor ops (ddim.py:339,348,353)."""
+    c = T // S
+    ddim_timesteps = np.asarray(list(range(0, T, c))) + 1
+    ac = alphas_cumprod.cpu()
+    alphas = ac[ddim_timesteps]                                   # float32 tensor
+    alphas_prev = np.asarray([ac[0]] + ac[ddim_timesteps[:-1]].tolist())  # float64 ndarray
+    # util.py:88-90 mixes a float32 torch tensor (alphas) with a float64 ndarray (alphas_prev); the
+    # operand types are kept exactly so numpy/torch promotion reproduces the reference bit for bit.
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    sigmas = np.asarray(sigmas, dtype=np.float64)
+    sqrt_one_minus = np.sqrt(1.0 - alphas.numpy())               # float32 (ddim.py:84)
+    rows = []
+    for i in range(len(ddim_timesteps)):
+        a_t = torch.full((1,), float(alphas[i]))
+        a_prev = torch.full((1,), float(alphas_prev[i]))
+        sigma = torch.full((1,), float(sigmas[i]))
+        som = torch.full((1,), float(sqrt_one_minus[i]))
+        rows.append(torch.cat([som, a_t.sqrt(), (1.0 - a_prev - sigma ** 2).sqrt(), a_prev.sqrt(), sigma]))
+    return ddim_timesteps, torch.stack(rows)
+
+
+@torch.no_grad()
+def ddim_sample(apply_model: Callable, shape, cond, uncond=None, guidance: float = 1.0, S: int = 200,
+                eta: float = 1.0, alphas_cumprod: Optional[torch.Tensor] = None, x_T=None,
+                record: Optional[list] = None):
+    """ddim.py:166-262 / 265-355.  apply_model(x, t[B] long, cond) -> eps.  Returns x_0 latent."""
+    if alphas_cumprod is None:
+        alphas_cumprod = make_schedule_buffers()["alphas_cumprod"]
+    ts, coef = ddim_tables(alphas_cumprod, S, eta, alphas_cumprod.shape[0])
+    b = shape[0]
+    img = torch.randn(shape) if x_T is None else x_T
+    total = len(ts)
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        t = torch.full((b,), int(step), dtype=torch.long)
+        if uncond is None or guidance == 1.0:
+            e_t = apply_model(img, t, cond)
+        else:
+            e_u = apply_model(img, t, uncond)
+            e_c = apply_model(img, t, cond)
+            e_t = e_u + guidance * (e_c - e_u)
+        c0, c1, c2, c3, c4 = [coef[index, j] for j in range(5)]
+        pred_x0 = (img - c0 * e_t) / c1
+        dir_xt = c2 * e_t
+        noise = c4 * torch.randn(img.shape)
+        img = c3 * pred_x0 + dir_xt + noise
+        if record is not None:
+            record.append(img.clone())
+    return img

@@ -1,0 +1,213 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference with the
+import stubs of oracle/refimport.py) on the seeded cases of oracle/cases.py.  TEST INFRA ONLY; run
+in the build container:  python -m oracle.make_golden [all|unet|vae|hifigan|ddim|stft|e2e5|e2e200]
+
+The reference ships no golden vectors; these fixtures are what pins both the oracle
+restatement (tests/test_oracle.py, CPU) and the HIP product (tests/test_*_gpu.py) to the reference.
+Weights are the deterministic name-keyed tensors of oracle/weights.py loaded through the reference
+modules' own load_state_dict.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from oracle import cases, refimport, weights
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"  wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def load_det(module, seed=0):
+    sd = weights.make_state_dict(weights.shapes_of(module), seed=seed)
+    module.load_state_dict(sd)
+    return sd
+
+
+def gen_unet():
+    U = refimport.unet_cls()
+    keys = {}
+    for name, cfg, B, H, W, t5 in [("unet_tiny", cases.UNET_TINY, 2, 16, 8, 12),
+                                   ("unet_large_tiny", cases.UNET_LARGE_TINY, 2, 16, 8, 12),
+                                   ("unet_film_tiny", cases.UNET_FILM_TINY, 2, 8, 16, 12),
+                                   ("unet_full", cases.UNET_FULL, 1, 256, 16, 32)]:
+        torch.manual_seed(0)
+        ref = U(**cfg).eval()
+        load_det(ref)
+        keys[name] = {k: list(v) for k, v in weights.shapes_of(ref).items()}
+        x, t, ctxs, masks, y = cases.unet_inputs(cfg, B, H, W, t5)
+        t0 = time.time()
+        with torch.no_grad():
+            out = ref(x, t, y=y, context_list=ctxs, context_attn_mask_list=masks)
+        print(f"{name}: ref forward {time.time()-t0:.1f}s out std {out.std():.4f}")
+        save(name, out=out)
+    with open(os.path.join(OUT, "unet_statedict_keys.json"), "w") as f:
+        json.dump(keys, f)
+
+
+def _ref_autoencoder(dd):
+    refimport.install()
+    from audioldm2.latent_encoder.autoencoder import AutoencoderKL
+    return AutoencoderKL(ddconfig=dd, embed_dim=dd["z_channels"], image_key="fbank").eval()
+
+
+def gen_vae():
+    keys = {}
+    for name, dd, shapes in [("vae16k", cases.DDCONFIG_16K, [(2, 8, 32, 16), (1, 8, 256, 16)]),
+                             ("vae48k", cases.DDCONFIG_48K, [(1, 16, 16, 32)])]:
+        ae = _ref_autoencoder(dd)
+        load_det(ae)
+        keys[name] = {k: list(v) for k, v in weights.shapes_of(ae).items()}
+        arrs = {}
+        for i, shp in enumerate(shapes):
+            z = cases.latent_input(*shp, seed=i)
+            t0 = time.time()
+            with torch.no_grad():
+                mel = ae.decode(z)
+            print(f"{name} decode {shp}: {time.time()-t0:.1f}s  mel std {mel.std():.3f} mean {mel.mean():.3f}")
+            arrs[f"mel{i}"] = mel
+        # encoder: moments of a random mel (posterior mean/logvar before sampling)
+        f = 2 ** (len(dd["ch_mult"]) - 1)
+        x = cases.mel_input(1, dd["mel_bins"], 16 * f, seed=5).permute(0, 2, 1)[:, None]  # [1,1,T,F]
+        with torch.no_grad():
+            post = ae.encode(x)
+        arrs["moments"] = post.parameters
+        save(name, **arrs)
+    with open(os.path.join(OUT, "vae_statedict_keys.json"), "w") as fjs:
+        json.dump(keys, fjs)
+
+
+def gen_hifigan():
+    for name, hc, Ts in [("hifigan16k", cases.HIFIGAN_16K, [48, 1024]), ("hifigan48k", cases.HIFIGAN_48K, [24])]:
+        g = refimport.hifigan_generator(dict(hc))
+        load_det(g)
+        arrs = {}
+        for i, T in enumerate(Ts):
+            mel = cases.mel_input(1, hc["num_mels"], T, seed=i)
+            t0 = time.time()
+            with torch.no_grad():
+                w = g(mel)
+            print(f"{name} T={T}: {time.time()-t0:.1f}s wave {tuple(w.shape)} rms {w.pow(2).mean().sqrt():.4f} absmax {w.abs().max():.3f}")
+            arrs[f"wave{i}"] = w
+        save(name, **arrs)
+
+
+def gen_ddim():
+    D = refimport.ddim_sampler_cls()
+    from oracle.ddim import make_schedule_buffers
+
+    class Shim:
+        pass
+    buf = make_schedule_buffers(1000, 0.0015, 0.0195)
+    m = Shim()
+    m.num_timesteps = 1000
+    m.betas, m.alphas_cumprod, m.alphas_cumprod_prev = buf["betas"], buf["alphas_cumprod"], buf["alphas_cumprod_prev"]
+    m.device = torch.device("cpu")
+    arrs = {}
+    for S, eta in [(200, 1.0), (50, 0.0), (5, 1.0)]:
+        s = D(m, device=torch.device("cpu"))
+        s.make_schedule(S, ddim_eta=eta, verbose=False)
+        arrs[f"ts_{S}"] = s.ddim_timesteps
+        arrs[f"alphas_{S}"] = s.ddim_alphas
+        arrs[f"alphas_prev_{S}"] = s.ddim_alphas_prev
+        arrs[f"sigmas_{S}"] = s.ddim_sigmas
+        arrs[f"som_{S}"] = s.ddim_sqrt_one_minus_alphas
+    save("ddim_tables", **arrs)
+
+
+def gen_stft():
+    """The reference STFT needs librosa (absent).  pad_center is the identity for win == n_fft (both
+    AudioLDM2 configs) and the mel filterbank is the oracle's restatement of librosa 0.9.2 (parity
+    UNPINNED for the filterbank); everything else below is the reference's own code running."""
+    refimport.install()
+    from oracle import stft as ostft
+    lib = sys.modules.get("librosa") or __import__("librosa")
+    sys.modules["librosa.util"].pad_center = lambda w, size, **k: w if len(w) == size else np.pad(
+        w, ((size - len(w)) // 2, size - len(w) - (size - len(w)) // 2))
+    sys.modules["librosa.util"].tiny = lambda x: np.finfo(np.float32).tiny
+    sys.modules["librosa.filters"].mel = lambda sr, n_fft, n_mels, fmin, fmax: ostft.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    for mod in ("audioldm2.utilities.audio.stft", "audioldm2.utilities.audio.audio_processing"):
+        sys.modules.pop(mod, None)
+    from audioldm2.utilities.audio.stft import TacotronSTFT
+    st = TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000)
+    x = cases.wave_input(2, 16000, seed=0)
+    mel, mag, phase, energy = st.mel_spectrogram(x)
+    print("stft: mel", tuple(mel.shape), "mag max", float(mag.max()))
+    save("stft16k", mel=mel, mag=mag, energy=energy, mel_basis=st.mel_basis, basis_head=st.stft_fn.forward_basis[:8, 0, :])
+
+
+def _ref_latent_diffusion():
+    refimport.install()
+    import audioldm2.utils as ru
+    from audioldm2.latent_diffusion.models.ddpm import LatentDiffusion
+    P = ru.default_audioldm_config("audioldm2-full")["model"]["params"]
+    P["cond_stage_config"] = cases.e2e_cond_config("cpu")
+    P["device"] = "cpu"
+    torch.manual_seed(0)
+    ld = LatentDiffusion(**P).eval()
+    sd = ld.state_dict()
+    hot = {k: tuple(v.shape) for k, v in sd.items()
+           if k.startswith("model.diffusion_model.") or k.startswith("first_stage_model.")}
+    new = weights.make_state_dict(hot, seed=0)
+    new["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    missing, unexpected = ld.load_state_dict(new, strict=False)
+    assert not unexpected
+    with open(os.path.join(OUT, "e2e_statedict_keys.json"), "w") as f:
+        json.dump({k: list(v) for k, v in hot.items()}, f)
+    return ld
+
+
+def gen_e2e(steps: int, B: int, name: str):
+    ld = _ref_latent_diffusion()
+    ld.latent_t_size = 256
+    rec = {}
+    orig_decode = ld.decode_first_stage
+
+    def decode_hook(z):
+        rec["latent"] = z.clone()
+        mel = orig_decode(z)
+        rec["mel"] = mel.clone()
+        return mel
+    ld.decode_first_stage = decode_hook
+    # seed_everything(42) of pipeline.py:20-31
+    import random
+    random.seed(cases.E2E_SEED)
+    np.random.seed(cases.E2E_SEED)
+    torch.manual_seed(cases.E2E_SEED)
+    t0 = time.time()
+    wav = ld.generate_batch(cases.e2e_batch(B), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1,
+                            duration=10)
+    dt = time.time() - t0
+    print(f"{name}: reference generate_batch B={B} steps={steps}: {dt:.1f}s  wave {wav.shape} rms {np.sqrt((wav**2).mean()):.4f}"
+          f" absmax {np.abs(wav).max():.3f}  latent std {rec['latent'].std():.3f}")
+    save(name, latent=rec["latent"], mel=rec["mel"], wave=wav, seconds=np.float32(dt), threads=np.int32(torch.get_num_threads()))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["all"]
+    torch.set_grad_enabled(False)
+    if "all" in what or "ddim" in what:
+        gen_ddim()
+    if "all" in what or "unet" in what:
+        gen_unet()
+    if "all" in what or "vae" in what:
+        gen_vae()
+    if "all" in what or "hifigan" in what:
+        gen_hifigan()
+    if "all" in what or "stft" in what:
+        gen_stft()
+    if "all" in what or "e2e5" in what:
+        gen_e2e(5, 2, "e2e_full_5step_b2")
+    if "e2e200" in what:
+        gen_e2e(200, 1, "e2e_full_200step_b1")

@@ -1,0 +1,72 @@
+"""Oracle: the whole text-to-audio sampling path on the CPU, assembled from the functional
+restatements (oracle/unet.py, vae.py, ddim.py).  TEST INFRA ONLY — the checker for parity tests,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of bench.py; never on the product path.
+
+Restates LatentDiffusion.generate_batch (models/ddpm.py:1477-1570) for n_gen = 1:
+  get_input (ddpm.py:830-897): posterior sample of the encoded zero mel -> only its RNG draw matters,
+  conditioners -> cond dict, unconditional conds, sample_log -> DDIMSampler.sample,
+  decode_first_stage (ddpm.py:922-926), mel_spectrogram_to_waveform (ddpm.py:928-939),
+  apply_model / DiffusionWrapper.forward routing (ddpm.py:1034-1042, 1821-1879).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import cases, weights
+from .ddim import ddim_sample, make_schedule_buffers
+from .unet import unet_forward
+from .vae import hifigan_forward, vae_decode
+
+_GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def hot_path_shapes(model_name: str = "audioldm2-full") -> Dict[str, tuple]:
+    """Names/shapes of the reference's hot-path tensors (recorded from the real LatentDiffusion)."""
+    assert model_name == "audioldm2-full"
+    with open(os.path.join(_GOLD, "e2e_statedict_keys.json")) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+class OracleLatentDiffusion:
+    def __init__(self, sd: Optional[Dict[str, torch.Tensor]] = None, unet_cfg=None, ddconfig=None,
+                 hifigan_cfg=None, scale_factor: float = cases.SCALE_FACTOR, t5_len: int = 32, seed: int = 0):
+        self.unet_cfg = unet_cfg or cases.UNET_FULL
+        self.dd = ddconfig or cases.DDCONFIG_16K
+        self.hcfg = hifigan_cfg or cases.HIFIGAN_16K
+        self.sd = sd if sd is not None else weights.make_state_dict(hot_path_shapes(), seed=seed)
+        self.scale_factor = scale_factor
+        self.buffers = make_schedule_buffers(1000, 0.0015, 0.0195)
+        from audioldm2_amd.pipeline import instantiate_from_config
+        cond_cfg = cases.e2e_cond_config("cpu", t5_len)
+        self.cond_keys = list(cond_cfg.keys())
+        self.cond_models = {k: instantiate_from_config(v) for k, v in cond_cfg.items()}
+        self.cond_stage_key = {k: v["cond_stage_key"] for k, v in cond_cfg.items()}
+        self.channels, self.latent_t_size, self.latent_f_size = 8, 256, 16
+
+    def apply_model(self, x, t, cond):
+        ctxs = [cond[k][0] for k in self.cond_keys]
+        masks = [cond[k][1] for k in self.cond_keys]
+        return unet_forward(self.sd, self.unet_cfg, x, t, ctxs, masks, prefix="model.diffusion_model.")
+
+    @torch.no_grad()
+    def generate_batch(self, batch, unconditional_guidance_scale=3.5, ddim_steps=200, ddim_eta=1.0,
+                       record: Optional[list] = None):
+        B = batch["log_mel_spec"].shape[0]
+        torch.randn((B, 8, batch["log_mel_spec"].shape[1] // 4, batch["log_mel_spec"].shape[2] // 4))  # posterior draw
+        cond = {k: m(batch if self.cond_stage_key[k] == "all" else batch[self.cond_stage_key[k]])
+                for k, m in self.cond_models.items()}
+        uncond = None
+        if unconditional_guidance_scale != 1.0:
+            uncond = {k: m.get_unconditional_condition(B) for k, m in self.cond_models.items()}
+        shape = (B, self.channels, self.latent_t_size, self.latent_f_size)
+        z = ddim_sample(self.apply_model, shape, cond, uncond, unconditional_guidance_scale, ddim_steps,
+                        ddim_eta, self.buffers["alphas_cumprod"], record=record)
+        zs = (1.0 / torch.tensor(self.scale_factor)) * z  # ddpm.py:924 (fp32 buffer arithmetic)
+        mel = vae_decode(self.sd, self.dd, zs, prefix="first_stage_model.")
+        wave = hifigan_forward(self.sd, self.hcfg, mel.squeeze(1).permute(0, 2, 1),
+                               prefix="first_stage_model.vocoder.")
+        return {"latent": z, "mel": mel, "wave": wave.numpy()}

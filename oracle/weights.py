@@ -1,0 +1,57 @@
+"""Deterministic synthetic weights, keyed by parameter NAME (test infrastructure).
+
+No checkpoint is reachable offline, and the reference's own constructors are not available on the
+GPU box, so every parity run uses weights that any party can regenerate from (name, shape, seed):
+the real reference modules in the build container (oracle/make_golden.py), this oracle, and the
+HIP product modules all load the same tensors through their ordinary `load_state_dict`.
+
+Magnitudes follow PyTorch's default initialisers (kaiming_uniform(a=sqrt(5)) => U(-1/sqrt(fan_in),
++1/sqrt(fan_in)) for conv/linear weights and biases; norm gains near 1) so activations stay O(1).
+The reference zero-initialises some tensors (`zero_module`, openaimodel.py:255,810, attention.py:452)
+which would make a fresh UNet output exactly 0; here they get ordinary random values like any
+trained checkpoint would have.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+
+def _gen(name: str, seed: int) -> torch.Generator:
+    g = torch.Generator()
+    g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 62))
+    return g
+
+
+def make_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, gain: float = 1.0) -> torch.Tensor:
+    g = _gen(name, seed)
+    shape = tuple(int(s) for s in shape)
+    if len(shape) == 0:
+        return torch.ones(())
+    leaf = name.rsplit(".", 1)[-1]
+    if len(shape) >= 2:
+        if "ups." in name and len(shape) == 3:
+            # ConvTranspose1d [Cin, Cout, k]: each output sees Cin*k/stride taps ~ use Cin*k/4
+            fan_in = shape[0] * shape[2] / 4.0
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+        bound = gain / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+    # 1-D: norm gain, or bias
+    if leaf == "weight":
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    return 0.05 * torch.randn(shape, generator=g)
+
+
+def make_state_dict(shapes: Dict[str, Iterable[int]], seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """shapes: {parameter name: shape} (e.g. from `module.state_dict()`); returns fp32 CPU tensors."""
+    return {k: make_tensor(k, tuple(v), seed, gain) for k, v in shapes.items()}
+
+
+def shapes_of(module: torch.nn.Module) -> Dict[str, Tuple[int, ...]]:
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}

@@ -1,0 +1,261 @@
+"""GPU parity tests proper: the HIP product (through the C ABI) against
+  (1) the committed fixtures produced by the REAL reference (tests/golden, oracle/make_golden.py),
+  (2) the CPU oracle on fresh seeded inputs,
+  (3) size-independent properties at the BASELINE batch (batch-invariance, determinism,
+      CFG-batched == two passes, HIP-graph replay == eager).
+Tolerances are stated next to each assert: module-level max-norm relative error 2e-4 (fp32, different
+accumulation order over ~50 chained layers); waveform after 200 DDIM steps: RMS error < 1e-3 (the
+north-star bound) and relative RMS < 1e-2.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, weights
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MOD_TOL = 2e-4
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rms(a):
+    a = np.asarray(a, dtype=np.float64)
+    return float(np.sqrt((a ** 2).mean()))
+
+
+def load_det(module, seed=0):
+    module.load_state_dict(weights.make_state_dict(weights.shapes_of(module), seed=seed))
+    return module
+
+
+def cu(x):
+    if x is None:
+        return None
+    if isinstance(x, (list, tuple)):
+        return [cu(e) for e in x]
+    return x.cuda()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,cfg,B,H,W,t5", [
+    ("unet_tiny", cases.UNET_TINY, 2, 16, 8, 12),
+    ("unet_large_tiny", cases.UNET_LARGE_TINY, 2, 16, 8, 12),
+    ("unet_film_tiny", cases.UNET_FILM_TINY, 2, 8, 16, 12),
+    ("unet_full", cases.UNET_FULL, 1, 256, 16, 32),
+])
+def test_unet_matches_reference_fixture(name, cfg, B, H, W, t5):
+    from audioldm2_amd.unet import UNetModel
+    m = load_det(UNetModel(**cfg))
+    x, t, ctxs, masks, y = cases.unet_inputs(cfg, B, H, W, t5)
+    out = m(x.cuda(), t.cuda(), y=cu(y), context_list=cu(ctxs), context_attn_mask_list=cu(masks))
+    e = rel(out, gold(name)["out"])
+    print(f"{name}: rel err vs reference fixture {e:.2e}")
+    assert e < MOD_TOL
+
+
+def test_unet_full_vs_oracle_batch8_properties():
+    """BASELINE batch (8 prompts, CFG => 16 rows): agrees with the CPU oracle on two rows, is
+    batch-invariant (row b of the batch-16 pass == the same row run alone) and deterministic."""
+    from audioldm2_amd.unet import UNetModel
+    from oracle.unet import unet_forward
+    cfg = cases.UNET_FULL
+    m = load_det(UNetModel(**cfg))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x, t, ctxs, masks, _ = cases.unet_inputs(cfg, 16, 256, 16, 32, seed=3)
+    out = m(x.cuda(), t.cuda(), context_list=cu(ctxs), context_attn_mask_list=cu(masks))
+    out2 = m(x.cuda(), t.cuda(), context_list=cu(ctxs), context_attn_mask_list=cu(masks))
+    assert torch.equal(out, out2), "non-deterministic UNet forward"
+    for b in (0, 11):
+        sl = slice(b, b + 1)
+        ref = unet_forward(sd, cfg, x[sl], t[sl], [c[sl] for c in ctxs], [mm[sl] for mm in masks])
+        assert rel(out[sl], ref) < MOD_TOL
+        alone = m(x[sl].cuda(), t[sl].cuda(), context_list=cu([c[sl] for c in ctxs]),
+                  context_attn_mask_list=cu([mm[sl] for mm in masks]))
+        assert rel(alone, out[sl]) < 1e-5  # same kernels; only tile/grid shapes differ
+
+
+@pytest.mark.parametrize("name,dd,shapes", [("vae16k", cases.DDCONFIG_16K, [(2, 8, 32, 16), (1, 8, 256, 16)]),
+                                            ("vae48k", cases.DDCONFIG_48K, [(1, 16, 16, 32)])])
+def test_vae_matches_reference_fixture(name, dd, shapes):
+    from audioldm2_amd.vae import AutoencoderKL
+    ae = load_det(AutoencoderKL(ddconfig=dd, embed_dim=dd["z_channels"], image_key="fbank"))
+    g = gold(name)
+    for i, shp in enumerate(shapes):
+        mel = ae.decode(cases.latent_input(*shp, seed=i).cuda())
+        e = rel(mel, g[f"mel{i}"])
+        print(f"{name} decode {shp}: rel err {e:.2e}")
+        assert e < MOD_TOL
+    f = 2 ** (len(dd["ch_mult"]) - 1)
+    x = cases.mel_input(1, dd["mel_bins"], 16 * f, seed=5).permute(0, 2, 1)[:, None].contiguous()
+    post = ae.encode(x.cuda())
+    assert rel(post.parameters, g["moments"]) < MOD_TOL
+
+
+@pytest.mark.parametrize("name,hc,Ts", [("hifigan16k", cases.HIFIGAN_16K, [48, 1024]),
+                                        ("hifigan48k", cases.HIFIGAN_48K, [24])])
+def test_hifigan_matches_reference_fixture(name, hc, Ts):
+    from audioldm2_amd.hifigan import Generator
+    gen = load_det(Generator(dict(hc)))
+    g = gold(name)
+    for i, T in enumerate(Ts):
+        w = gen(cases.mel_input(1, hc["num_mels"], T, seed=i).cuda())
+        assert tuple(w.shape) == tuple(g[f"wave{i}"].shape)
+        e = rel(w, g[f"wave{i}"])
+        print(f"{name} T={T}: rel err {e:.2e}")
+        assert e < MOD_TOL
+
+
+def test_stft_mel_matches_reference_fixture_and_oracle():
+    from audioldm2_amd.stft import TacotronSTFT
+    from oracle import stft as ostft
+    st = TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000)
+    g = gold("stft16k")
+    assert np.array_equal(st.mel_basis.numpy(), g["mel_basis"])
+    x = cases.wave_input(2, 16000, seed=0)
+    mel, mag, phase, energy = st.mel_spectrogram(x)
+    assert rel(mag, g["mag"]) < 5e-5 and rel(energy, g["energy"]) < 5e-5
+    assert float((mel - torch.from_numpy(g["mel"])).abs().max()) < 2e-3  # log of clamped values
+    # full 10.24 s clip (BASELINE shape [B, 163840]) against the oracle, incl. phase where |X| is not tiny
+    x = cases.wave_input(2, 163840, seed=1)
+    mel, mag, phase, energy = st.mel_spectrogram(x)
+    omel, omag, ophase, oen = ostft.mel_spectrogram(x)
+    assert tuple(mel.shape) == (2, 64, 1025) and rel(mag, omag) < 5e-5
+    big = omag > 1e-2 * omag.max()
+    dphi = torch.remainder(phase - ophase + np.pi, 2 * np.pi) - np.pi
+    assert float(dphi[big].abs().max()) < 1e-3
+    st48 = TacotronSTFT(2048, 480, 2048, 256, 48000, 20, 24000)
+    x48 = cases.wave_input(1, 48000, seed=2)
+    mel48 = st48.mel_spectrogram(x48)[0]
+    omel48 = ostft.mel_spectrogram(x48, 2048, 480, 2048, 256, 48000, 20, 24000)[0]
+    assert float((mel48 - omel48).abs().max()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------
+def _build_ld(t5_len=32):
+    from audioldm2_amd.pipeline import build_model
+    ld = build_model(model_name="audioldm2-full")
+    with open(os.path.join(GOLD, "e2e_statedict_keys.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = weights.make_state_dict(shapes, seed=0)
+    sd["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    ld.load_state_dict(sd, strict=False)
+    return ld.cuda()
+
+
+@pytest.fixture(scope="module")
+def ld():
+    return _build_ld()
+
+
+def _report(tag, out, g):
+    errs = {}
+    for k in ("latent", "mel", "wave"):
+        a = np.asarray(out[k].detach().cpu() if torch.is_tensor(out[k]) else out[k], dtype=np.float64)
+        b = g[k].astype(np.float64)
+        errs[k] = (rms(a - b), rms(b))
+    print(f"{tag}: " + "  ".join(f"{k}: rms_err {e:.3e} / rms_ref {r:.3e} (rel {e/r:.2e})" for k, (e, r) in errs.items()))
+    return errs
+
+
+def _generate(ld, B, steps):
+    from audioldm2_amd.pipeline import seed_everything
+    rec = {}
+    orig = ld.decode_first_stage_cl
+
+    def hook(z):
+        rec["latent"] = z.clone()
+        mel = orig(z)
+        rec["mel"] = mel.view(mel.shape[0], 1, mel.shape[1], mel.shape[2]).clone()
+        return mel
+    ld.decode_first_stage_cl = hook
+    try:
+        seed_everything(cases.E2E_SEED)
+        ld.latent_t_size = 256
+        rec["wave"] = ld.generate_batch(cases.e2e_batch(B), unconditional_guidance_scale=3.5,
+                                        ddim_steps=steps, n_gen=1, duration=10)
+    finally:
+        ld.decode_first_stage_cl = orig
+    return rec
+
+
+def test_e2e_5step_matches_reference_generate_batch(ld):
+    """Whole path vs the real LatentDiffusion.generate_batch fixture (B=2, 5 steps, CFG 3.5, seed 42):
+    RNG contract, CFG batching with padded/masked contexts, DDIM update, VAE decode, vocoder."""
+    g = gold("e2e_full_5step_b2")
+    out = _generate(ld, 2, 5)
+    assert out["wave"].dtype == np.float32 and out["wave"].shape == (2, 1, 163872)
+    errs = _report("e2e 5 steps B=2", out, g)
+    assert errs["latent"][0] / errs["latent"][1] < 1e-4
+    assert errs["mel"][0] / errs["mel"][1] < 1e-4
+    assert errs["wave"][0] < 1e-3 and errs["wave"][0] / errs["wave"][1] < 1e-3
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "e2e_full_200step_b1.npz")), reason="200-step fixture absent")
+def test_e2e_200step_waveform_within_north_star_tolerance(ld):
+    """BASELINE config 1 (1 prompt, 10 s, 200 DDIM steps, CFG 3.5, seed 42) against the reference's
+    CPU run: waveform RMS error < 1e-3 (north_star), relative RMS < 1e-2."""
+    g = gold("e2e_full_200step_b1")
+    out = _generate(ld, 1, 200)
+    errs = _report("e2e 200 steps B=1", out, g)
+    assert errs["wave"][0] < 1e-3
+    assert errs["wave"][0] / errs["wave"][1] < 1e-2
+    assert errs["latent"][0] / errs["latent"][1] < 1e-2
+
+
+def test_cfg_batched_equals_two_passes_and_graph_equals_eager(ld):
+    """apply_model_cfg (one 2B pass, padded + masked contexts) == two apply_model passes; the HIP
+    graph replay path == the eager path (same kernels, same order => bitwise)."""
+    B = 2
+    batch = cases.e2e_batch(B)
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(B)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    x = cases.latent_input(B, 8, 256, 16, seed=9).cuda()
+    t = torch.tensor([501, 501])
+    eps2 = ld.apply_model_cfg(x, t.float().repeat(2).cuda(), cond, uncond)
+    e_u = ld.apply_model(x, t.cuda(), uncond)
+    e_c = ld.apply_model(x, t.cuda(), cond)
+    assert rel(eps2[0], e_u) < 1e-5 and rel(eps2[1], e_c) < 1e-5
+    os.environ["ALDM_NO_GRAPH"] = "1"
+    try:
+        eager = _generate(ld, 2, 4)
+    finally:
+        os.environ["ALDM_NO_GRAPH"] = "0"
+    graph = _generate(ld, 2, 4)
+    assert torch.equal(eager["latent"], graph["latent"])
+
+
+def test_pipeline_batch8_runs_and_is_batch_consistent(ld):
+    """BASELINE config 2 shape (batch 8): finite output of the right shape; prompt 0 of the batch-8 run
+    equals the batch-1 run on the same noise (samples are independent: no cross-sample coupling)."""
+    out8 = _generate(ld, 8, 3)
+    assert out8["wave"].shape == (8, 1, 163872) and np.isfinite(out8["wave"]).all()
+    # batch-1 run draws a different global noise tensor, so compare through x_T injection instead
+    from audioldm2_amd.ddim import DDIMSampler
+    batch = cases.e2e_batch(8)
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(8)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    torch.manual_seed(5)
+    s8, _ = DDIMSampler(ld).sample(3, 8, (8, 256, 16), cond, eta=0.0, unconditional_guidance_scale=3.5,
+                                   unconditional_conditioning=uncond, verbose=False)
+    cond1 = {k: [v[0][:1].contiguous(), v[1][:1].contiguous()] for k, v in cond.items()}
+    unc1 = {k: [v[0][:1].contiguous(), v[1][:1].contiguous()] for k, v in uncond.items()}
+    torch.manual_seed(5)
+    xT = torch.randn(8, 8, 256, 16)[:1]
+    s1, _ = DDIMSampler(ld).sample(3, 1, (8, 256, 16), cond1, eta=0.0, unconditional_guidance_scale=3.5,
+                                   unconditional_conditioning=unc1, verbose=False, x_T=xT)
+    assert rel(s1, s8[:1]) < 1e-4

@@ -1,0 +1,126 @@
+"""CPU tests: the oracle restatement (oracle/*.py) against the fixtures that oracle/make_golden.py
+produced by running the REAL reference classes (tests/golden/*.npz).  This is what pins the oracle.
+Tolerance: the oracle performs the same ATen ops in the same order, so agreement is at fp32
+round-off of thread-count-dependent reductions: max|err| <= 2e-5 * max|ref| (usually exactly 0).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, weights
+from oracle.ddim import ddim_tables, make_schedule_buffers
+from oracle.unet import unet_forward
+from oracle.vae import hifigan_forward, vae_decode, vae_encode_moments
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 2e-5
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _shapes(fname, key):
+    import json
+    with open(os.path.join(GOLD, fname)) as f:
+        return {k: tuple(v) for k, v in json.load(f)[key].items()}
+
+
+@pytest.mark.parametrize("name,cfg,B,H,W,t5", [
+    ("unet_tiny", cases.UNET_TINY, 2, 16, 8, 12),
+    ("unet_large_tiny", cases.UNET_LARGE_TINY, 2, 16, 8, 12),
+    ("unet_film_tiny", cases.UNET_FILM_TINY, 2, 8, 16, 12),
+    ("unet_full", cases.UNET_FULL, 1, 256, 16, 32),
+])
+def test_unet_oracle_matches_reference_fixture(name, cfg, B, H, W, t5):
+    sd = weights.make_state_dict(_shapes("unet_statedict_keys.json", name), seed=0)
+    x, t, ctxs, masks, y = cases.unet_inputs(cfg, B, H, W, t5)
+    out = unet_forward(sd, cfg, x, t, ctxs, masks, y=y)
+    assert rel(out, gold(name)["out"]) < TOL
+
+
+@pytest.mark.parametrize("name,dd,shapes", [
+    ("vae16k", cases.DDCONFIG_16K, [(2, 8, 32, 16), (1, 8, 256, 16)]),
+    ("vae48k", cases.DDCONFIG_48K, [(1, 16, 16, 32)]),
+])
+def test_vae_oracle_matches_reference_fixture(name, dd, shapes):
+    sd = weights.make_state_dict(_shapes("vae_statedict_keys.json", name), seed=0)
+    g = gold(name)
+    for i, shp in enumerate(shapes):
+        mel = vae_decode(sd, dd, cases.latent_input(*shp, seed=i))
+        assert rel(mel, g[f"mel{i}"]) < TOL
+    f = 2 ** (len(dd["ch_mult"]) - 1)
+    x = cases.mel_input(1, dd["mel_bins"], 16 * f, seed=5).permute(0, 2, 1)[:, None]
+    assert rel(vae_encode_moments(sd, dd, x), g["moments"]) < TOL
+
+
+@pytest.mark.parametrize("name,hc,Ts", [("hifigan16k", cases.HIFIGAN_16K, [48, 1024]),
+                                        ("hifigan48k", cases.HIFIGAN_48K, [24])])
+def test_hifigan_oracle_matches_reference_fixture(name, hc, Ts):
+    shapes = {k: v for k, v in _shapes("vae_statedict_keys.json", "vae16k" if "16k" in name else "vae48k").items()
+              if k.startswith("vocoder.")}
+    sd = weights.make_state_dict({k[len("vocoder."):]: v for k, v in shapes.items()}, seed=0)
+    g = gold(name)
+    for i, T in enumerate(Ts):
+        w = hifigan_forward(sd, hc, cases.mel_input(1, hc["num_mels"], T, seed=i))
+        assert rel(w, g[f"wave{i}"]) < TOL
+
+
+def test_ddim_tables_match_reference_exactly():
+    """ddim.py:33-91 tables, including the reference's mixed float32/float64 arithmetic: bit-exact."""
+    g = gold("ddim_tables")
+    ac = make_schedule_buffers(1000, 0.0015, 0.0195)["alphas_cumprod"]
+    for S, eta in [(200, 1.0), (50, 0.0), (5, 1.0)]:
+        ts, coef = ddim_tables(ac, S, eta)
+        assert np.array_equal(ts, g[f"ts_{S}"])
+        a = torch.from_numpy(g[f"alphas_{S}"])
+        ap = torch.from_numpy(g[f"alphas_prev_{S}"])
+        sg = torch.from_numpy(g[f"sigmas_{S}"])
+        som = torch.from_numpy(g[f"som_{S}"])
+        for i in range(S):  # coefficient rows as p_sample_ddim forms them (ddim.py:330-353)
+            a_t = torch.full((1,), float(a[i]))
+            a_prev = torch.full((1,), float(ap[i]))
+            s_t = torch.full((1,), float(sg[i]))
+            ref = torch.cat([torch.full((1,), float(som[i])), a_t.sqrt(), (1.0 - a_prev - s_t ** 2).sqrt(),
+                             a_prev.sqrt(), s_t])
+            assert torch.equal(coef[i], ref), (S, i)
+    # SURVEY.md §8(a3) check values
+    _, c200 = ddim_tables(ac, 200, 1.0)
+    assert abs(float(c200[0, 4]) - 0.027432) < 1e-6 and abs(float(c200[199, 4]) - 0.305154) < 1e-6
+
+
+def test_stft_oracle_matches_reference_fixture():
+    """Reference TacotronSTFT (with the oracle's mel filterbank injected for the absent librosa)."""
+    from oracle import stft as ostft
+    g = gold("stft16k")
+    x = cases.wave_input(2, 16000, seed=0)
+    mel, mag, phase, energy = ostft.mel_spectrogram(x)
+    assert rel(mag, g["mag"]) < TOL and rel(mel, g["mel"]) < 1e-4 and rel(energy, g["energy"]) < TOL
+    assert np.array_equal(ostft.stft_forward_basis(1024, 1024)[:8], g["basis_head"])
+    # 440 Hz known answer: peak bin of the sine row = round(440 / (16000/1024)) = 28
+    assert int(mag[0, :, 50].argmax()) == 28
+    # filterbank sanity (librosa 0.9.2 defaults): 64 slaney filters, unit-area-ish normalisation
+    fb = ostft.mel_filterbank(16000, 1024, 64, 0, 8000)
+    assert fb.shape == (64, 513) and fb.min() >= 0 and (fb.sum(1) > 0).all()
+
+
+@pytest.mark.timeout(900)
+def test_e2e_oracle_matches_reference_generate_batch_5step():
+    """Whole path (RNG contract, conditioner routing, CFG, DDIM, VAE decode, vocoder) vs the real
+    LatentDiffusion.generate_batch fixture (B=2, 5 DDIM steps, CFG 3.5, seed 42)."""
+    from oracle.pipeline import OracleLatentDiffusion
+    g = gold("e2e_full_5step_b2")
+    o = OracleLatentDiffusion()
+    torch.manual_seed(cases.E2E_SEED)
+    out = o.generate_batch(cases.e2e_batch(2), unconditional_guidance_scale=3.5, ddim_steps=5)
+    assert rel(out["latent"], g["latent"]) < 1e-4
+    assert rel(out["mel"], g["mel"]) < 1e-4
+    assert rel(out["wave"], g["wave"]) < 1e-4
