@@ -320,9 +320,9 @@ static int log2_exact(int v) {
 
 using namespace aldm;
 
-extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
+// validation + derived quantities + tile selection, shared by aldm_igemm and aldm_igemm_plan
+static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN) {
     ALDM_CHECK(dd != nullptr, "aldm_igemm: null descriptor");
-    IgemmK p;
     p.d = *dd;
     aldm_igemm_desc& d = p.d;
     ALDM_CHECK(d.x1 && d.w && d.out, "aldm_igemm: null x1/w/out");
@@ -368,8 +368,8 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
 
     // tile selection: widest N tile that the layer fills; drop to BM=64 when the 128-row grid
     // would leave most of the 256 CUs idle (deep UNet levels at small batch).
-    int BN = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
-    int BM = 128;
+    BN = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+    BM = 128;
     if (BN >= 64) {
         const int64_t blocks128 = cdiv64(p.M, 128) * cdiv(d.N, BN) * d.batch;
         if (blocks128 < 512) BM = 64;
@@ -380,6 +380,26 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     }
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(d.N, BN);
+    return 0;
+}
+
+extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int64_t* flops) {
+    IgemmK p;
+    int BM, BN;
+    const int rc = igemm_prepare(dd, p, BM, BN);
+    if (rc) return rc;
+    if (bm) *bm = BM;
+    if (bn) *bn = BN;
+    if (flops) *flops = 2ll * p.M * p.d.N * p.d.K * p.d.batch;
+    return 0;
+}
+
+extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
+    IgemmK p;
+    int BM, BN;
+    const int rc = igemm_prepare(dd, p, BM, BN);
+    if (rc) return rc;
+    const aldm_igemm_desc& d = p.d;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)d.batch);
     hipStream_t st = (hipStream_t)stream;
 #define ALDM_IG(BM_, BN_, WM_, WN_) \

@@ -52,6 +52,8 @@ class DDIMSampler(object):
         self.schedule = schedule
         self.device = device
         self.use_graph = os.environ.get("ALDM_NO_GRAPH", "0") != "1"
+        # (global_batch, row_offset) when this process samples one shard of a larger batch (dist.py)
+        self.noise_shard = getattr(model, "noise_shard", None)
 
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
@@ -103,12 +105,19 @@ class DDIMSampler(object):
     def _draw_noise(self, shape, steps, x_T, with_mask):
         """Replays the reference's host RNG order: x_T, then per step [q_sample noise (inpainting
         only, ddim.py:228 / ddpm.py:430-436)], step noise (ddim.py:351)."""
-        img = torch.randn(shape) if x_T is None else x_T
+        if self.noise_shard is None:
+            draw = lambda: torch.randn(shape)
+        else:
+            # prompt-sharded run: draw the GLOBAL batch like the single-process reference, keep our rows
+            gB, off = self.noise_shard
+            gshape = (gB,) + tuple(shape[1:])
+            draw = lambda: torch.randn(gshape)[off:off + shape[0]].contiguous()
+        img = draw() if x_T is None else x_T
         step_noise, q_noise = [], []
         for _ in range(steps):
             if with_mask:
-                q_noise.append(torch.randn(shape))
-            step_noise.append(torch.randn(shape))
+                q_noise.append(draw())
+            step_noise.append(draw())
         return img, torch.stack(step_noise), (torch.stack(q_noise) if with_mask else None)
 
     @torch.no_grad()

@@ -47,6 +47,8 @@ _SIGS = {
     "aldm_version": (C.c_int, []),
     "aldm_last_error": (C.c_char_p, []),
     "aldm_igemm": (C.c_int, [C.POINTER(IgemmDesc), C.c_void_p]),
+    "aldm_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int64)]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_kn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -45,6 +45,26 @@ class Packed:
         return self.KH * self.KW * self.Cin
 
 
+# Optional profiling hook (bench.py's roofline leg): when PROFILE is a list, every igemm launch is
+# bracketed by events on the launch stream and recorded as (what, BM, BN, flops, ev_start, ev_end).
+PROFILE = None
+
+
+def _igemm(d: IgemmDesc, what: str):
+    lib = _l.load()
+    if PROFILE is None:
+        _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
+        return
+    bm, bn, fl = C.c_int(), C.c_int(), C.c_int64()
+    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl)), what)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
+    e1.record()
+    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1))
+
+
 def _npad(n: int) -> int:
     return (n + 31) // 32 * 32
 
@@ -140,7 +160,7 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.accumulate = 1 if accumulate else 0
     d.out_mul = out_mul; d.out_off = out_off; d.out_len = out_len
     d.batch = 1
-    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(conv)")
+    _igemm(d, "igemm(conv)")
     return out.view(oshape)
 
 
@@ -177,7 +197,7 @@ def gemm_nt(a: torch.Tensor, bmat: torch.Tensor, *, alpha: float = 1.0,
     d.w = bp; d.b_mode = B_NT; d.ldb = ldb; d.K = K; d.N = N
     d.out = out.data_ptr(); d.ldo = N; d.alpha = alpha
     d.batch = Z; d.stride_x = sa; d.stride_w = sb; d.stride_o = M * N
-    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(nt)")
+    _igemm(d, "igemm(nt)")
     return out
 
 
@@ -206,7 +226,7 @@ def gemm_packed_batched(a: torch.Tensor, bp: torch.Tensor, K: int, N: int, *,
     d.w = bp.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0; d.K = K; d.N = N
     d.out = out.data_ptr(); d.ldo = N; d.alpha = 1.0
     d.batch = Z; d.stride_x = M * K; d.stride_w = bp.shape[1]; d.stride_o = M * N
-    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(packed batched)")
+    _igemm(d, "igemm(packed batched)")
     return out
 
 
@@ -368,7 +388,7 @@ def frames_gemm(sig: torch.Tensor, frames: int, hop: int, pw: Packed) -> torch.T
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = K; d.N = pw.N
     d.out = out.data_ptr(); d.ldo = pw.N; d.alpha = 1.0
     d.batch = B; d.stride_x = pitch; d.stride_w = 0; d.stride_o = frames * pw.N
-    _l.check(_l.load().aldm_igemm(C.byref(d), _stream()), "igemm(frames)")
+    _igemm(d, "igemm(frames)")
     return out
 
 

@@ -392,11 +392,32 @@ class LatentDiffusion(nn.Module):
             for key, meta in self.cond_stage_model_metadata.items():
                 unconditional_conditioning[key] = self.cond_stage_models[
                     meta["model_idx"]].get_unconditional_condition(batch_size)
-        samples, _ = self.sample_log(cond=c, batch_size=batch_size, x_T=x_T, ddim=use_ddim,
-                                     ddim_steps=ddim_steps, eta=ddim_eta,
-                                     unconditional_guidance_scale=unconditional_guidance_scale,
-                                     unconditional_conditioning=unconditional_conditioning,
-                                     use_plms=use_plms)
+        shard = kwargs.get("shard", None)  # (rank, world): sample only this process's contiguous slice
+        self.noise_shard = None
+        if shard is not None:
+            from .dist import shard_range
+            assert n_gen == 1, "prompt sharding keeps a prompt's candidates together: use n_gen == 1 per shard"
+            lo, hi = shard_range(batch_size, shard[0], shard[1])
+
+            def cut(v):
+                if isinstance(v, (list, tuple)):
+                    return [cut(e) for e in v]
+                if isinstance(v, dict):
+                    return {kk: cut(vv) for kk, vv in v.items()}
+                return v[lo:hi].contiguous()
+            c = {k: cut(v) for k, v in c.items()}
+            if unconditional_conditioning is not None:
+                unconditional_conditioning = {k: cut(v) for k, v in unconditional_conditioning.items()}
+            self.noise_shard = (batch_size, lo)  # noise is drawn for the global batch, rows [lo, hi) kept
+            batch_size = hi - lo
+        try:
+            samples, _ = self.sample_log(cond=c, batch_size=batch_size, x_T=x_T, ddim=use_ddim,
+                                         ddim_steps=ddim_steps, eta=ddim_eta,
+                                         unconditional_guidance_scale=unconditional_guidance_scale,
+                                         unconditional_conditioning=unconditional_conditioning,
+                                         use_plms=use_plms)
+        finally:
+            self.noise_shard = None
         mel = self.decode_first_stage_cl(samples)  # [B, T, F, 1]
         waveform = self.mel_spectrogram_to_waveform(mel.view(mel.shape[0], mel.shape[1], mel.shape[2]),
                                                     savepath="", bs=None, name=batch.get("fname"), save=False)

@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X AudioLDM2 sampling path (BASELINE.json metric).
+
+One "step" = one whole job of the hot path over one batch of synthetic prompts:
+  sample_log (200 DDIM steps, CFG 3.5, eta 1.0) -> VAE decode -> HiFi-GAN -> waveform on the host
+for `audioldm2-full`, batch 8 prompts per GPU, 10.24 s of 16 kHz audio per prompt (BASELINE.json
+configs[1]); n_candidate_gen_per_text = 1; conditioners (out of scope) are synthetic and excluded.
+metric = audio-seconds / second (whole job, all GPUs).  Weak scaling: per-GPU batch fixed.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel, measured
+live with events on the launch stream) and `cpu_baseline` (the CPU oracle = the reference's
+arithmetic on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+AUDIO_SECONDS = 163872 / 16000.0  # delivered samples per prompt (10.242 s)
+UNET_GFLOP_PER_FWD_SAMPLE = 171.20  # SURVEY.md §8(d), audioldm2-full, L_T5 = 32
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="prompts per GPU")
+    ap.add_argument("--ddim-steps", type=int, default=200)
+    ap.add_argument("--model", default="audioldm2-full")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-ddim-steps", type=int, default=8)
+    return ap.parse_args()
+
+
+def roofline_probe(ld, batch, B):
+    """One eager DDIM step with every igemm launch bracketed by events on its stream.  Returns the
+    roofline dict for the dominant igemm instantiation and the list of per-tile aggregates."""
+    from audioldm2_amd import ops
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(B)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    x = torch.randn(B, ld.channels, ld.latent_t_size, ld.latent_f_size).cuda()
+    t2 = torch.full((2 * B,), 501.0).cuda()
+    ld.apply_model_cfg(x, t2, cond, uncond)  # warm
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    try:
+        ld.apply_model_cfg(x, t2, cond, uncond)
+        torch.cuda.synchronize()
+        prof = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    agg = {}
+    for what, bm, bn, fl, e0, e1 in prof:
+        a = agg.setdefault((bm, bn), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += fl
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    dom = max(agg.items(), key=lambda kv: kv[1][2])
+    (bm, bn), (n, fl, sec) = dom
+    achieved = fl / sec / 1e12
+    tot_fl = sum(v[1] for v in agg.values())
+    tot_s = sum(v[2] for v in agg.values())
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "kernel": f"aldm::igemm_kernel<{bm},{bn}>", "launches_per_unet_pass": n,
+        "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
+        "all_igemm_tflops": round(tot_fl / tot_s / 1e12, 2),
+        "all_igemm_launches": sum(v[0] for v in agg.values()),
+        "all_igemm_ms": round(tot_s * 1e3, 3),
+    }
+
+
+def unet_step_probe(ld, batch, B, steps=12):
+    """Secondary metric: ms per DDIM step (2 UNet evaluations as one 2B pass + fused update),
+    graph-replayed, timed with events over steps 2..steps-1."""
+    from audioldm2_amd.ddim import DDIMSampler
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(B)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    marks = []
+
+    def cb(i):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+    s = DDIMSampler(ld)
+    s.sample(20, B, (ld.channels, ld.latent_t_size, ld.latent_f_size), cond, eta=1.0,
+             unconditional_guidance_scale=3.5, unconditional_conditioning=uncond, verbose=False, callback=cb)
+    torch.cuda.synchronize()
+    return marks[3].elapsed_time(marks[-1]) / (len(marks) - 4)
+
+
+def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
+    """The CPU oracle (the reference's own ATen arithmetic restated, oracle/pipeline.py) on this box's
+    host cores: B = 1, `ddim_steps_sample` DDIM steps + VAE decode + vocoder, loop extrapolated to
+    `total_steps`.  run_cpu.py itself (diffusers, Hub weights) cannot run offline."""
+    from oracle import cases
+    from oracle.ddim import ddim_sample
+    from oracle.pipeline import OracleLatentDiffusion
+    from oracle.vae import hifigan_forward, vae_decode
+    o = OracleLatentDiffusion()
+    threads = torch.get_num_threads()
+    batch = cases.e2e_batch(1)
+    cond = {k: m(batch if o.cond_stage_key[k] == "all" else batch[o.cond_stage_key[k]]) for k, m in o.cond_models.items()}
+    uncond = {k: m.get_unconditional_condition(1) for k, m in o.cond_models.items()}
+    torch.manual_seed(0)
+    ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, 5, 1.0, o.buffers["alphas_cumprod"])  # warm (1 step pair x5 is cheap enough)
+    t0 = time.time()
+    z = ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, ddim_steps_sample, 1.0, o.buffers["alphas_cumprod"])
+    t_loop = time.time() - t0
+    t0 = time.time()
+    mel = vae_decode(o.sd, o.dd, z / o.scale_factor, prefix="first_stage_model.")
+    t_dec = time.time() - t0
+    t0 = time.time()
+    hifigan_forward(o.sd, o.hcfg, mel.squeeze(1).permute(0, 2, 1), prefix="first_stage_model.vocoder.")
+    t_voc = time.time() - t0
+    step_s = t_loop / ddim_steps_sample
+    total = step_s * total_steps + t_dec + t_voc
+    return {"value": round(AUDIO_SECONDS / total, 5), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": (f"CPU oracle (torch fp32, {threads} threads), B=1: {ddim_steps_sample} DDIM steps timed "
+                       f"({step_s*1e3:.0f} ms/step) x{total_steps} extrapolated + VAE decode {t_dec:.2f}s + "
+                       f"vocoder {t_voc:.2f}s"),
+            "unet_step_ms": round(step_s * 1e3, 1)}
+
+
+def main():
+    args = parse()
+    from audioldm2_amd import dist as adist
+    from audioldm2_amd.pipeline import build_model, make_batch_for_text_to_audio, seed_everything
+    rank, world, local = adist.init_distributed()
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    torch.manual_seed(1234)  # random-init weights of the named architecture (no checkpoints offline)
+    ld = build_model(model_name=args.model).to(dev)
+    ld.scale_factor.fill_(0.75) if torch.is_tensor(ld.scale_factor) else None
+    bcast_bytes = adist.broadcast_module(ld, src=0)  # one RCCL broadcast of the hot-path weights
+
+    B = args.batch
+    gB = B * world
+    batch = make_batch_for_text_to_audio("synthetic prompt", batchsize=gB)
+    shard = (rank, world) if world > 1 else None
+
+    def job():
+        return ld.generate_batch(batch, unconditional_guidance_scale=3.5, ddim_steps=args.ddim_steps, n_gen=1,
+                                 duration=10, shard=shard)
+
+    seed_everything(42)
+    ld.latent_t_size = 256 if "48k" not in args.model else 128
+    for _ in range(args.warmup):
+        job()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = job()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert wav.shape == (B, 1, 163872) and np.isfinite(wav).all()
+
+    if rank == 0:
+        value = gB * AUDIO_SECONDS * args.steps / dt
+        out = {
+            "metric": "audio_seconds_per_second", "value": round(value, 3), "unit": "audio-s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model}: batch {B} prompts/GPU x {world} GPU, 10.24 s @16 kHz, "
+                                   f"{args.ddim_steps} DDIM steps, CFG 3.5, eta 1.0, n_candidates 1; one step = "
+                                   "sample_log + VAE decode + HiFi-GAN + D2H of the waveform; synthetic "
+                                   "conditioning (T5 length 32), random-init weights, host-CPU RNG noise",
+                       "global_batch": gB, "parallelism": f"prompt-sharded replicas x{world}",
+                       "weight_broadcast_bytes": bcast_bytes},
+        }
+        try:
+            step_ms = unet_step_probe(ld, make_batch_for_text_to_audio("synthetic prompt", batchsize=B), B)
+            out["unet_step_ms"] = round(step_ms, 3)
+            out["unet_step_tflops"] = round(2 * UNET_GFLOP_PER_FWD_SAMPLE * B / step_ms, 2)  # GFLOP/ms = TFLOP/s
+            out["unet_step_frac_of_f32_mfma_peak"] = round(out["unet_step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+        except Exception as e:  # pragma: no cover
+            out["unet_step_ms"] = f"probe failed: {e}"
+        if not args.no_roofline:
+            out["roofline"] = roofline_probe(ld, make_batch_for_text_to_audio("synthetic prompt", batchsize=B), B)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(1, args.cpu_ddim_steps, args.ddim_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

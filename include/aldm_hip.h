@@ -101,6 +101,9 @@ typedef struct aldm_igemm_desc {
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
+/* Host-only query (no launch): the block tile aldm_igemm would pick for this descriptor and the
+ * algorithmic FLOPs of the call (2*M*N*K*batch) — used by bench.py's roofline accounting.      */
+int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1

@@ -1,0 +1,80 @@
+"""CPU tests of the N>1 path with the gloo backend, world_size 2 (the 8-GPU run is the driver's):
+weight broadcast in flat buckets, contiguous prompt sharding, and the RNG contract under sharding
+(per-rank noise slices concatenate to the single-process noise)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from audioldm2_amd import dist as adist
+    from audioldm2_amd.ddim import DDIMSampler
+    r, w, _ = adist.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    # 1) bucketed weight broadcast: rank 0's values arrive everywhere, packed caches are dropped
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Conv2d(8, 8, 3), torch.nn.GroupNorm(4, 8))
+    net[0]._pk = "stale"
+    sent = adist.broadcast_tensors(list(net.parameters()), src=0, bucket_bytes=4096)  # forces several buckets
+    adist.broadcast_module(net, src=0)
+    assert sent == sum(p.numel() * 4 for p in net.parameters()) and net[0]._pk is None
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Conv2d(8, 8, 3), torch.nn.GroupNorm(4, 8))
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    # 2) sharding: contiguous, disjoint, covering
+    lo, hi = adist.shard_range(7, rank, world)
+    # 3) RNG contract: this rank's noise rows == rows [lo, hi) of the single-process draw
+
+    class M:
+        num_timesteps = 1000
+        noise_shard = (7, lo)
+    s = DDIMSampler(M())
+    torch.manual_seed(42)
+    img, noise, _ = s._draw_noise((hi - lo, 8, 4, 4), 3, None, False)
+    torch.save({"lo": lo, "hi": hi, "img": img, "noise": noise}, os.path.join(out_dir, f"r{rank}.pt"))
+    # 4) result gather in rank order
+    import numpy as np
+    got = adist.gather_waveforms(np.full((hi - lo, 1, 5), float(rank), dtype=np.float32), dst=0)
+    if rank == 0:
+        assert got.shape == (7, 1, 5) and got[:, 0, 0].tolist() == [0.0] * 4 + [1.0] * 3
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_broadcast_shard_and_noise_contract(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    assert (parts[0]["lo"], parts[0]["hi"], parts[1]["lo"], parts[1]["hi"]) == (0, 4, 4, 7)
+    torch.manual_seed(42)
+    full = [torch.randn(7, 8, 4, 4) for _ in range(4)]
+    assert torch.equal(torch.cat([p["img"] for p in parts]), full[0])
+    for i in range(3):
+        assert torch.equal(torch.cat([p["noise"][i] for p in parts]), full[i + 1])
+
+
+def test_shard_range_properties():
+    from audioldm2_amd.dist import shard_range
+    for n in (1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            rs = [shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
