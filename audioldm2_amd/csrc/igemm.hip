@@ -1,251 +1,45 @@
-// igemm.hip — implicit-GEMM convolution / GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
-//
-// One engine for every contraction of the AudioLDM2 sampling path (see include/aldm_hip.h):
-//   out[m, n] = epi( sum_k A[m, k] * W[k, n] ),  m = (b, oh, ow), k = (kh, kw, ci)
-//
-// Design (MI355X-first, not a port of any cuDNN/ATen algorithm):
-//  * activations are channels-last, so 4 consecutive k of one tap are one 16-byte load and a
-//    1x1 conv, a Linear and a conv tap are the same gather;
-//  * block tile BM x BN x 32, 4 wave64 (one per SIMD); each wave owns MT x NT MFMA 32x32 tiles
-//    (16 accumulator VGPRs each);
-//  * LDS image is k-group major: As[kg][row] / Bs[kg][col] hold float4 = 4 consecutive k, so one
-//    conflict-free ds_read_b128 feeds 4 MFMAs.  The K index inside the 8-wide sub-step is
-//    permuted (lane half h takes k = 4h..4h+3) — legal because A and B use the same permutation;
-//  * global -> register prefetch of tile t+1 is issued before the MFMA block of tile t
-//    (fp32 MFMA is 64 cycles/instruction: one tile = 4096 MFMA cycles per SIMD hides HBM/L2);
-//  * prologue fusion: GroupNorm apply (+SiLU) / leaky_relu on the gathered operand, skip-concat
-//    (two source tensors), nearest upsample; epilogue fusion: bias, timestep-embedding row bias,
-//    activation, residual, accumulate, strided row remap (polyphase transposed conv);
-//  * blockIdx is remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles.
-#include "common.h"
+// igemm.hip — host side of the implicit-GEMM engine: validation, tile / split-K selection, launch,
+// split-K reduce kernel, weight packing.  The device kernel lives in igemm_kernel.h and is
+// instantiated per prologue mode in igemm_pre{0..4}.hip (parallel compilation).
+#include "igemm_kernel.h"
+#include <algorithm>
 
 namespace aldm {
 
-struct IgemmK {
-    aldm_igemm_desc d;
-    int Cin, M, OHW, HV, WV, shh, shw, Kg, Npad, tiles_m, tiles_n;
-};
+// per-prologue launchers (igemm_pre*.hip)
+int igemm_launch_pre0(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre1(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre2(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre3(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre4(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 
-constexpr int BK = 32;
-constexpr int KG = BK / 4;
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
-    constexpr int MT = BM / (32 * WM);
-    constexpr int NT = BN / (32 * WN);
-    constexpr int PA = BM / 32;  // A-loader passes (32 rows x 8 k-groups per pass)
-    constexpr int PB = BN / 32;  // B-loader passes
-    static_assert(WM * WN == 4, "4 waves");
-    __shared__ f32x4 As[KG][BM + 1];
-    __shared__ f32x4 Bs[KG][BN + 1];
-
+// split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
+// quad (N % 4 == 0 is required for split-K).
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
     const aldm_igemm_desc& d = p.d;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-
-    // XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8)
-    int tile_m, tile_n;
-    {
-        const int nwg = gridDim.x;
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tile_n = logical % p.tiles_n;
-        tile_m = logical / p.tiles_n;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
-    const float* x1 = d.x1 + (int64_t)z * d.stride_x;
-    const float* x2 = d.x2 ? d.x2 + (int64_t)z * d.stride_x : nullptr;
-    const float* wgt = d.w + (int64_t)z * d.stride_w;
-
-    // ---- A loader bookkeeping: this thread gathers rows r0 + 32*pp, k-group akg ----
-    const int akg = tid & 7;
-    const int ar0 = tid >> 3;
-    int a_b[PA], a_h[PA], a_w[PA];
-#pragma unroll
-    for (int pp = 0; pp < PA; ++pp) {
-        const int m = m0 + ar0 + 32 * pp;
-        if (m < p.M) {
-            const int b = m / p.OHW;
-            const int rem = m - b * p.OHW;
-            const int oh = rem / d.OW;
-            const int ow = rem - oh * d.OW;
-            a_b[pp] = b;
-            a_h[pp] = oh * d.SH - d.PH;
-            a_w[pp] = ow * d.SW - d.PW;
-        } else {
-            a_b[pp] = 0;
-            a_h[pp] = -(1 << 28);
-            a_w[pp] = 0;
-        }
+    const int N4 = d.N >> 2;
+    const int64_t total = (int64_t)p.M * N4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int m = (int)(i / N4);
+    const int n = (int)(i - (int64_t)m * N4) << 2;
+    const int64_t slab = (int64_t)p.M * d.N;
+    const float* w = d.ws + (int64_t)z * p.splits * slab + (int64_t)m * d.N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(w);
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(w + s * slab);
+    const int b = m / p.OHW;
+    int64_t orow = m;
+    if (d.out_mul > 0) {
+        const int qq = m - b * p.OHW;
+        const int t = qq * d.out_mul + d.out_off;
+        if ((unsigned)t >= (unsigned)d.out_len) return;
+        orow = (int64_t)b * d.out_len + t;
     }
-    const int pix1 = d.pix1, pix2 = d.pix2;
-    const bool has_pre = d.pre_scale != nullptr;
-    const int pre_act = d.pre_act;
-    const float pre_slope = d.pre_slope;
-
-    f32x4 ra[PA], rb[PB];
-
-    auto load_a = [&](int k0) {
-        const int k = k0 + 4 * akg;
-        const bool kval = k < d.K;
-        const int tap = kval ? k / p.Cin : 0;
-        const int ci = kval ? k - tap * p.Cin : 0;
-        const int kh = tap / d.KW;
-        const int kw = tap - kh * d.KW;
-        const bool first = ci < d.C1;
-        const float* src = first ? x1 : x2;
-        const int c = first ? ci : ci - d.C1;
-        const int pitch = first ? pix1 : pix2;
-        const int dh = kh * d.DH, dw = kw * d.DW;
-#pragma unroll
-        for (int pp = 0; pp < PA; ++pp) {
-            const int ihv = a_h[pp] + dh;
-            const int iwv = a_w[pp] + dw;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kval && (unsigned)ihv < (unsigned)p.HV && (unsigned)iwv < (unsigned)p.WV) {
-                const int ih = ihv >> p.shh, iw = iwv >> p.shw;
-                const int64_t off = ((int64_t)(a_b[pp] * d.H + ih) * d.W + iw) * pitch + c;
-                v = *reinterpret_cast<const f32x4*>(src + off);
-                if (has_pre) {
-                    const int64_t so = (int64_t)a_b[pp] * p.Cin + ci;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
-                    v = v * sc + sh;
-                }
-                if (pre_act != ALDM_ACT_NONE) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], pre_act, pre_slope);
-                }
-            }
-            ra[pp] = v;
-        }
-    };
-
-    auto load_b = [&](int k0) {
-        if (d.b_mode == ALDM_B_PACKED) {
-            const int n = tid % BN;
-            const int kg0 = tid / BN;
-            constexpr int step = 256 / BN;
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                const int kg = (k0 >> 2) + kg0 + step * pp;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kg < p.Kg && n0 + n < p.Npad)
-                    v = *reinterpret_cast<const f32x4*>(wgt + ((int64_t)kg * p.Npad + n0 + n) * 4);
-                rb[pp] = v;
-            }
-        } else {  // NT: Bmat[N][ldb]
-            const int kg = tid & 7;
-            const int r0 = tid >> 3;
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                const int n = n0 + r0 + 32 * pp;
-                const int k = k0 + 4 * kg;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < d.N && k < d.K)
-                    v = *reinterpret_cast<const f32x4*>(wgt + (int64_t)n * d.ldb + k);
-                rb[pp] = v;
-            }
-        }
-    };
-
-    auto store_lds = [&]() {
-#pragma unroll
-        for (int pp = 0; pp < PA; ++pp) As[akg][ar0 + 32 * pp] = ra[pp];
-        if (d.b_mode == ALDM_B_PACKED) {
-            const int n = tid % BN;
-            const int kg0 = tid / BN;
-            constexpr int step = 256 / BN;
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) Bs[kg0 + step * pp][n] = rb[pp];
-        } else {
-            const int kg = tid & 7;
-            const int r0 = tid >> 3;
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) Bs[kg][r0 + 32 * pp] = rb[pp];
-        }
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = (d.K + BK - 1) / BK;
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
-
-    load_a(0);
-    load_b(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        store_lds();
-        __syncthreads();
-        if (kt + 1 < nk) {
-            load_a((kt + 1) * BK);
-            load_b((kt + 1) * BK);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int kg = 2 * s + lh;
-            f32x4 af[MT], bf[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = As[kg][(wm * MT + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = Bs[kg][(wn * NT + j) * 32 + l31];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                          acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue ----
     float* outp = d.out + (int64_t)z * d.stride_o;
     const float* resp = d.res ? d.res + (int64_t)z * d.stride_o : nullptr;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const int m = m0 + row;
-            if (m >= p.M) continue;
-            const int b = m / p.OHW;
-            int64_t orow = m;
-            if (d.out_mul > 0) {
-                const int qq = m - b * p.OHW;
-                const int t = qq * d.out_mul + d.out_off;
-                if ((unsigned)t >= (unsigned)d.out_len) continue;
-                orow = (int64_t)b * d.out_len + t;
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + (wn * NT + j) * 32 + l31;
-                if (n >= d.N) continue;
-                float v = acc[i][j][e];
-                if (d.bias) v += d.bias[n];
-                if (d.rowbias) v += d.rowbias[(int64_t)b * d.N + n];
-                v = act_apply(v, d.act, d.act_slope);
-                const int64_t o = orow * d.ldo + n;
-                if (resp) v += resp[o];
-                v *= d.alpha;
-                if (d.accumulate) v += outp[o];
-                outp[o] = v;
-            }
-        }
-    }
+    for (int j = 0; j < 4; ++j) epi_store(d, p.rb_ld, outp, resp, b, orow, n + j, v[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -320,7 +114,19 @@ static int log2_exact(int v) {
 
 using namespace aldm;
 
-// validation + derived quantities + tile selection, shared by aldm_igemm and aldm_igemm_plan
+static thread_local int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+
+extern "C" void aldm_igemm_force(int bm, int bn, int splits) {
+    g_force_bm = bm;
+    g_force_bn = bn;
+    g_force_splits = splits;
+}
+
+static bool tile_supported(int BM, int BN) {
+    return (BM == 128 && (BN == 128 || BN == 64 || BN == 32)) || (BM == 64 && (BN == 128 || BN == 64));
+}
+
+// validation + derived quantities + tile / split-K selection, shared by aldm_igemm and the queries
 static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN) {
     ALDM_CHECK(dd != nullptr, "aldm_igemm: null descriptor");
     p.d = *dd;
@@ -358,32 +164,67 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     if (d.out_mul > 0) ALDM_CHECK(d.OH == 1, "aldm_igemm: row remap requires OH == 1");
     ALDM_CHECK((d.pre_scale == nullptr) == (d.pre_shift == nullptr),
                "aldm_igemm: pre_scale/pre_shift must come together");
+    ALDM_CHECK(d.pre_scale == nullptr ||
+                   ((reinterpret_cast<uintptr_t>(d.pre_scale) | reinterpret_cast<uintptr_t>(d.pre_shift)) & 15) == 0,
+               "aldm_igemm: pre_scale/pre_shift must be 16-byte aligned");
     p.OHW = d.OH * d.OW;
     const int64_t M64 = (int64_t)d.B * p.OHW;
     ALDM_CHECK(M64 < (1ll << 31) - 256, "aldm_igemm: M too large");
     p.M = (int)M64;
     p.HV = d.H * d.up_h;
     p.WV = d.W * d.up_w;
+    ALDM_CHECK((int64_t)d.B * d.H * d.W < (1ll << 31), "aldm_igemm: input has too many pixels");
     p.Kg = (d.K + 3) / 4;
+    p.rb_ld = d.rowbias_ld > 0 ? d.rowbias_ld : d.N;
 
-    // tile selection: widest N tile that the layer fills; drop to BM=64 when the 128-row grid
-    // would leave most of the 256 CUs idle (deep UNet levels at small batch).
-    BN = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
-    BM = 128;
-    if (BN >= 64) {
-        const int64_t blocks128 = cdiv64(p.M, 128) * cdiv(d.N, BN) * d.batch;
-        if (blocks128 < 512) BM = 64;
-    }
-    if (BM == 64 && BN == 128) {
-        const int64_t blocks = cdiv64(p.M, 64) * cdiv(d.N, 128) * d.batch;
-        if (blocks < 256 && d.N % 64 == 0) BN = 64;
+    // ---- tile selection -------------------------------------------------------------------
+    // widest N tile the layer fills; 128-row tiles unless that grid cannot give every CU two
+    // blocks (deep UNet levels at small batch), then 64-row tiles, then split-K.
+    const int nk = (d.K + BK - 1) / BK;
+    if (g_force_bm) {
+        BM = g_force_bm;
+        BN = g_force_bn;
+        ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm_force: unsupported tile %dx%d", BM, BN);
+    } else {
+        BN = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+        BM = 128;
+        if (BN >= 64) {
+            const int64_t blocks128 = cdiv64(p.M, 128) * cdiv(d.N, BN) * d.batch;
+            if (blocks128 < 512) BM = 64;
+        }
+        if (BM == 64 && BN == 128) {
+            const int64_t blocks = cdiv64(p.M, 64) * cdiv(d.N, 128) * d.batch;
+            if (blocks < 256 && d.N % 64 == 0) BN = 64;
+        }
     }
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(d.N, BN);
+    // ---- split-K ----------------------------------------------------------------------------
+    int splits = 1;
+    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * d.batch;
+    const bool can_split = d.N % 4 == 0 && nk >= 8;
+    if (g_force_splits > 0) {
+        splits = can_split ? g_force_splits : 1;
+    } else if (can_split && blocks < 384) {
+        const int want = (BM == 64 && BN == 64) ? 1024 : 512;  // resident blocks the chip can hold
+        splits = (int)std::min<int64_t>(cdiv64(want, blocks), 16);
+        splits = std::min(splits, nk / 4);  // >= 4 k-tiles per split
+    }
+    if (splits < 1) splits = 1;
+    p.kt_per_split = cdiv(nk, splits);
+    splits = cdiv(nk, p.kt_per_split);  // no empty split
+    if (splits > 1) {
+        const int64_t need = (int64_t)d.batch * splits * p.M * d.N;
+        if (d.ws == nullptr || d.ws_floats < need || (reinterpret_cast<uintptr_t>(d.ws) & 15)) {
+            splits = 1;
+            p.kt_per_split = nk;
+        }
+    }
+    p.splits = splits;
     return 0;
 }
 
-extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int64_t* flops) {
+extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int64_t* flops, int* splits) {
     IgemmK p;
     int BM, BN;
     const int rc = igemm_prepare(dd, p, BM, BN);
@@ -391,29 +232,52 @@ extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int6
     if (bm) *bm = BM;
     if (bn) *bn = BN;
     if (flops) *flops = 2ll * p.M * p.d.N * p.d.K * p.d.batch;
+    if (splits) *splits = p.splits;
     return 0;
+}
+
+extern "C" int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* dd) {
+    if (!dd) return 0;
+    // ask with an "infinite" dummy workspace to learn the split the heuristic wants
+    aldm_igemm_desc t = *dd;
+    t.ws = reinterpret_cast<float*>(uintptr_t(16));
+    t.ws_floats = INT64_MAX;
+    IgemmK p;
+    int BM, BN;
+    if (igemm_prepare(&t, p, BM, BN)) return 0;
+    return p.splits > 1 ? (int64_t)p.d.batch * p.splits * p.M * p.d.N : 0;
 }
 
 extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     IgemmK p;
     int BM, BN;
-    const int rc = igemm_prepare(dd, p, BM, BN);
+    int rc = igemm_prepare(dd, p, BM, BN);
     if (rc) return rc;
     const aldm_igemm_desc& d = p.d;
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)d.batch);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits, (unsigned)d.batch);
     hipStream_t st = (hipStream_t)stream;
-#define ALDM_IG(BM_, BN_, WM_, WN_) \
-    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_>), grid, dim3(256), 0, st, p)
-    if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2);
-    else if (BM == 128 && BN == 64) ALDM_IG(128, 64, 2, 2);
-    else if (BM == 128 && BN == 32) ALDM_IG(128, 32, 4, 1);
-    else if (BM == 64 && BN == 128) ALDM_IG(64, 128, 2, 2);
-    else if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2);
-    else {
+    int pre;
+    if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_NONE;
+    else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_AFFINE;
+    else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_SILU) pre = PRE_AFFINE_SILU;
+    else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) pre = PRE_LRELU;
+    else pre = PRE_GENERIC;
+    switch (pre) {
+        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, grid, st, p); break;
+        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, grid, st, p); break;
+        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, grid, st, p); break;
+        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, grid, st, p); break;
+        default: rc = igemm_launch_pre4(BM, BN, grid, st, p); break;
+    }
+    if (rc) {
         set_error("aldm_igemm: no kernel for tile %dx%d", BM, BN);
         return -1;
     }
-#undef ALDM_IG
+    if (p.splits > 1) {
+        const int64_t total = (int64_t)p.M * (d.N >> 2);
+        hipLaunchKernelGGL(igemm_reduce_kernel, dim3((unsigned)cdiv64(total, 256), 1, (unsigned)d.batch),
+                           dim3(256), 0, st, p);
+    }
     ALDM_LAUNCH_CHECK("aldm_igemm");
     return 0;
 }

@@ -1,0 +1,418 @@
+// igemm_kernel.h — the implicit-GEMM convolution / GEMM kernel on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   out[m, n] = epi( sum_k A[m, k] * W[k, n] ),  m = (b, oh, ow), k = (kh, kw, ci)
+//
+// Design (MI355X-first, not a port of any cuDNN/ATen algorithm):
+//  * activations are channels-last, so 4 consecutive k of one tap are one 16-byte load and a
+//    1x1 conv, a Linear and a conv tap are the same gather;
+//  * block tile BM x BN x 32, 4 wave64 (one per SIMD); each wave owns MT x NT MFMA 32x32 tiles
+//    (16 accumulator VGPRs each);
+//  * LDS image is k-group major: As[kg][row] / Bs[kg][col] hold float4 = 4 consecutive k, so one
+//    conflict-free ds_read_b128 feeds 4 MFMAs.  The K index inside the 8-wide sub-step is
+//    permuted (lane half h takes k = 4h..4h+3) — legal because A and B use the same permutation;
+//  * software pipeline, ONE barrier per k-tile: LDS is double buffered; the global loads of tile
+//    t+1 are issued (branch-free: clamped addresses + a validity mask) before the MFMAs of tile t,
+//    their prologue transform + ds_write into the other buffer happens between the two halves of
+//    the MFMA block.  fp32 MFMA is 64 cycles/instruction, so one tile = 1024..4096 MFMA cycles per
+//    SIMD: HBM/L2 latency and the prologue VALU sit in that shadow;
+//  * the prologue is a template parameter (no runtime switch in the loop): GroupNorm apply
+//    (+SiLU), leaky_relu; skip-concat (two source tensors), nearest upsample, stride, dilation
+//    and padding are part of the address generation; (tap, ci) are tracked incrementally;
+//  * split-K (blockIdx.y): raw partial tiles go to a workspace, igemm_reduce_kernel sums them
+//    in a fixed order and applies the epilogue (deterministic, no atomics);
+//  * epilogue fusion: bias, timestep-embedding row bias, activation, residual, scale, accumulate,
+//    strided row remap (polyphase transposed conv);
+//  * blockIdx is remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles.
+#pragma once
+#include "common.h"
+
+namespace aldm {
+
+struct IgemmK {
+    aldm_igemm_desc d;
+    int Cin, M, OHW, HV, WV, shh, shw, Kg, Npad, tiles_m, tiles_n;
+    int splits, kt_per_split;  // split-K: k-tiles [s*kt_per_split, ...) per blockIdx.y
+    int rb_ld;                 // row-bias pitch
+};
+
+enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4 };
+
+constexpr int BK = 32;
+constexpr int KG = BK / 4;
+
+// one output element through the fused epilogue (shared by the GEMM kernel and the split-K reduce)
+__device__ __forceinline__ void epi_store(const aldm_igemm_desc& d, int rb_ld, float* __restrict__ outp,
+                                          const float* __restrict__ resp, int b, int64_t orow, int n,
+                                          float v) {
+    if (d.bias) v += d.bias[n];
+    if (d.rowbias) v += d.rowbias[(int64_t)b * rb_ld + n];
+    v = act_apply(v, d.act, d.act_slope);
+    const int64_t o = orow * d.ldo + n;
+    if (resp) v += resp[o];
+    v *= d.alpha;
+    if (d.accumulate) v += outp[o];
+    outp[o] = v;
+}
+
+__device__ __forceinline__ float silu_fast(float v) {
+    // x * sigmoid(x); v_exp_f32 / v_rcp_f32 are <= 1 ulp each: ~1e-7 relative, far inside the
+    // parity tolerance, and 5 VALU ops instead of the ~25 of expf + IEEE division.
+    return v * __frcp_rn(1.0f + __expf(-v));
+}
+
+template <int BM, int BN, int WM, int WN, int PRE>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
+    constexpr int MT = BM / (32 * WM);
+    constexpr int NT = BN / (32 * WN);
+    constexpr int PA = BM / 32;  // A-loader passes (32 rows x 8 k-groups per pass)
+    constexpr int PB = BN / 32;  // B-loader passes
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ f32x4 As[2][KG][BM + 1];
+    __shared__ f32x4 Bs[2][KG][BN + 1];
+
+    const aldm_igemm_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8)
+    int tile_m, tile_n;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = logical % p.tiles_n;
+        tile_m = logical / p.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const int split = blockIdx.y;
+    const float* x1 = d.x1 + (int64_t)z * d.stride_x;
+    const float* x2 = d.x2 ? d.x2 + (int64_t)z * d.stride_x : x1;
+    const float* wgt = d.w + (int64_t)z * d.stride_w;
+
+    const int nk_all = (d.K + BK - 1) / BK;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_all, kt0 + p.kt_per_split);
+
+    // ---- A loader bookkeeping: this thread gathers rows ar0 + 32*pp, k-group akg ----
+    const int akg = tid & 7;
+    const int ar0 = tid >> 3;
+    int a_pix[PA], a_h[PA], a_w[PA], a_b[PA];
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) {
+        const int m = m0 + ar0 + 32 * pp;
+        if (m < p.M) {
+            const int b = m / p.OHW;
+            const int rem = m - b * p.OHW;
+            const int oh = rem / d.OW;
+            const int ow = rem - oh * d.OW;
+            a_b[pp] = b;
+            a_pix[pp] = b * d.H;
+            a_h[pp] = oh * d.SH - d.PH;
+            a_w[pp] = ow * d.SW - d.PW;
+        } else {
+            a_b[pp] = 0;
+            a_pix[pp] = 0;
+            a_h[pp] = -(1 << 28);
+            a_w[pp] = 0;
+        }
+    }
+    // incremental (kh, kw, ci) of this thread's k = kt*BK + 4*akg
+    int t_ci, t_kh, t_kw;
+    {
+        const int k = kt0 * BK + 4 * akg;
+        const int tap = k / p.Cin;
+        t_ci = k - tap * p.Cin;
+        t_kh = tap / d.KW;
+        t_kw = tap - t_kh * d.KW;
+    }
+    const int pix1 = d.pix1, pix2 = d.pix2;
+
+    // ---- B loader bookkeeping ----
+    // PACKED: thread -> column n = tid % BN, k-groups kgb0 + stepb*pp ; NT: row r0 + 32*pp, k-group tid & 7
+    constexpr int stepb = 256 / BN;
+    const bool packed = d.b_mode == ALDM_B_PACKED;
+    const int bn_col = tid % BN;
+    const int bkg0 = tid / BN;
+
+    f32x4 ra[PA], rb[PB];
+    f32x4 rsc[(PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) ? PA : 1];
+    f32x4 rsh[(PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) ? PA : 1];
+    unsigned avalid = 0, bvalid = 0;
+
+    auto issue_loads = [&](int kt) {
+        // ---- A: branch-free gather (invalid -> offset 0, masked at commit time) ----
+        const bool kval = t_kh < d.KH;  // k < K
+        const bool first = t_ci < d.C1;
+        const float* src = first ? x1 : x2;
+        const int c = first ? t_ci : t_ci - d.C1;
+        const int pitch = first ? pix1 : pix2;
+        const int dh = t_kh * d.DH, dw = t_kw * d.DW;
+        avalid = 0;
+#pragma unroll
+        for (int pp = 0; pp < PA; ++pp) {
+            const int ihv = a_h[pp] + dh;
+            const int iwv = a_w[pp] + dw;
+            const bool ok = kval && (unsigned)ihv < (unsigned)p.HV && (unsigned)iwv < (unsigned)p.WV;
+            const int ih = ihv >> p.shh, iw = iwv >> p.shw;
+            const int pix = ok ? (a_pix[pp] + ih) * d.W + iw : 0;
+            const int64_t off = ok ? (int64_t)pix * pitch + c : 0;
+            ra[pp] = *reinterpret_cast<const f32x4*>(src + off);
+            avalid |= (ok ? 1u : 0u) << pp;
+            if constexpr (PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) {
+                if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
+                    const int64_t so = ok ? (int64_t)a_b[pp] * p.Cin + t_ci : 0;
+                    rsc[pp] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
+                    rsh[pp] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
+                }
+            }
+        }
+        // advance (kh, kw, ci) by one k-tile
+        t_ci += BK;
+        while (t_ci >= p.Cin) {
+            t_ci -= p.Cin;
+            if (++t_kw == d.KW) {
+                t_kw = 0;
+                ++t_kh;
+            }
+        }
+        // ---- B ----
+        bvalid = 0;
+        if (packed) {
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                const int kg = kt * KG + bkg0 + stepb * pp;
+                const bool ok = kg < p.Kg && n0 + bn_col < p.Npad;
+                const int64_t off = ok ? ((int64_t)kg * p.Npad + n0 + bn_col) * 4 : 0;
+                rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
+                bvalid |= (ok ? 1u : 0u) << pp;
+            }
+        } else {  // NT: Bmat[N][ldb]
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                const int n = n0 + ar0 + 32 * pp;
+                const int k = kt * BK + 4 * akg;
+                const bool ok = n < d.N && k < d.K;
+                const int64_t off = ok ? (int64_t)n * d.ldb + k : 0;
+                rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
+                bvalid |= (ok ? 1u : 0u) << pp;
+            }
+        }
+    };
+
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int pp = 0; pp < PA; ++pp) {
+            f32x4 v = ra[pp];
+            if constexpr (PRE == PRE_AFFINE) {
+                v = v * rsc[pp] + rsh[pp];
+            } else if constexpr (PRE == PRE_AFFINE_SILU) {
+                v = v * rsc[pp] + rsh[pp];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_fast(v[j]);
+            } else if constexpr (PRE == PRE_LRELU) {
+                const float sl = d.pre_slope;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : v[j] * sl;
+            } else if constexpr (PRE == PRE_GENERIC) {
+                if (d.pre_scale != nullptr) v = v * rsc[pp] + rsh[pp];
+                if (d.pre_act != ALDM_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], d.pre_act, d.pre_slope);
+                }
+            }
+            if (!((avalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
+            As[buf][akg][ar0 + 32 * pp] = v;
+        }
+        if (packed) {
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                f32x4 v = rb[pp];
+                if (!((bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                Bs[buf][bkg0 + stepb * pp][bn_col] = v;
+            }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                f32x4 v = rb[pp];
+                if (!((bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                Bs[buf][akg][ar0 + 32 * pp] = v;
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    auto mma_half = [&](int buf, int half) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kg = 2 * (2 * half + s2) + lh;
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = As[buf][kg][(wm * MT + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = Bs[buf][kg][(wn * NT + j) * 32 + l31];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                          acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (kt0 < kt1) {
+        issue_loads(kt0);
+        commit(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt + 1 < kt1; ++kt) {
+            issue_loads(kt + 1);
+            mma_half(buf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            commit(buf ^ 1);
+            mma_half(buf, 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        mma_half(buf, 0);  // last tile: nothing left to stage
+        mma_half(buf, 1);
+    }
+
+    // ---- epilogue ----
+    if (p.splits > 1) {
+        // raw partial tile -> workspace [z][split][M][N]
+        float* wsp = d.ws + ((int64_t)z * p.splits + split) * (int64_t)p.M * d.N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = n0 + (wn * NT + j) * 32 + l31;
+                    if (n < d.N) wsp[(int64_t)m * d.N + n] = acc[i][j][e];
+                }
+            }
+        return;
+    }
+    // Fused epilogue, restructured for memory-level parallelism: per 32-row slab all row offsets are
+    // computed first, then every optional operand (row bias, residual, previous output) is fetched
+    // with unconditional loads from clamped addresses (no branch + wait per element), then the math,
+    // then the stores.  v = act(acc + bias + rowbias); v = alpha*(v + res); out = acc ? out + v : v
+    float* outp = d.out + (int64_t)z * d.stride_o;
+    const float* resp = d.res ? d.res + (int64_t)z * d.stride_o : nullptr;
+    const bool need_b = d.rowbias != nullptr || d.out_mul > 0;
+    int ncl[NT];
+    bool nok[NT];
+    float biasv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + (wn * NT + j) * 32 + l31;
+        nok[j] = n < d.N;
+        ncl[j] = nok[j] ? n : 0;
+        biasv[j] = 0.f;
+    }
+    if (d.bias) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) biasv[j] = d.bias[ncl[j]];
+    }
+#pragma unroll
+    for (int ih = 0; ih < 2 * MT; ++ih) {  // 16-row half slabs: 8 accumulator rows per lane
+        const int i = ih >> 1, e0 = (ih & 1) * 8;
+        int64_t rowoff[8];
+        int rboff[8];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ee = e0 + e;
+            const int m = m0 + (wm * MT + i) * 32 + (ee & 3) + 8 * (ee >> 2) + 4 * lh;
+            bool ok = m < p.M;
+            int b = 0;
+            int64_t orow = m;
+            if (need_b) {
+                b = m / p.OHW;
+                if (d.out_mul > 0) {
+                    const int qq = m - b * p.OHW;
+                    const int t = qq * d.out_mul + d.out_off;
+                    ok = ok && (unsigned)t < (unsigned)d.out_len;
+                    orow = (int64_t)b * d.out_len + t;
+                }
+            }
+            rowoff[e] = ok ? orow * d.ldo : 0;
+            rboff[e] = ok ? b * p.rb_ld : 0;
+            okmask |= (ok ? 1u : 0u) << e;
+        }
+        float v[8][NT];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) v[e][j] = acc[i][j][e0 + e] + biasv[j];
+        if (d.rowbias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[e][j] += d.rowbias[rboff[e] + ncl[j]];
+        }
+        switch (d.act) {
+            case ALDM_ACT_NONE: break;
+            case ALDM_ACT_SILU:
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) v[e][j] = act_apply(v[e][j], ALDM_ACT_SILU, 0.f);
+                break;
+            case ALDM_ACT_GELU:
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) v[e][j] = act_apply(v[e][j], ALDM_ACT_GELU, 0.f);
+                break;
+            default:
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) v[e][j] = act_apply(v[e][j], d.act, d.act_slope);
+                break;
+        }
+        if (resp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[e][j] += resp[rowoff[e] + ncl[j]];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) v[e][j] *= d.alpha;
+        if (d.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[e][j] += outp[rowoff[e] + ncl[j]];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (((okmask >> e) & 1u) && nok[j]) outp[rowoff[e] + ncl[j]] = v[e][j];
+    }
+}
+
+}  // namespace aldm

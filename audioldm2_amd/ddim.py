@@ -167,11 +167,14 @@ class DDIMSampler(object):
         noise_cur = noise[0].clone()
 
         cfg_fused = use_cfg and hasattr(self.model, "apply_model_cfg")
+        prepared = self.model.prepare_cfg(cond, unconditional_conditioning) \
+            if cfg_fused and hasattr(self.model, "prepare_cfg") else None
 
         def step():
             if use_cfg:
                 if cfg_fused:
-                    eps = self.model.apply_model_cfg(x_cur, t_cur, cond, unconditional_conditioning)
+                    eps = self.model.apply_model_cfg(x_cur, t_cur, cond, unconditional_conditioning,
+                                                     prepared=prepared)
                 else:
                     tl = t_cur[:b].long()
                     e_u = self.model.apply_model(x_cur, tl, unconditional_conditioning)

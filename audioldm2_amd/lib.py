@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaldm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
 B_PACKED, B_NT = 0, 1
@@ -40,6 +40,8 @@ class IgemmDesc(C.Structure):
         ("out_mul", C.c_int32), ("out_off", C.c_int32), ("out_len", C.c_int32),
         ("batch", C.c_int32),
         ("stride_x", C.c_int64), ("stride_w", C.c_int64), ("stride_o", C.c_int64),
+        ("rowbias_ld", C.c_int32), ("reserved0", C.c_int32),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 
@@ -48,7 +50,9 @@ _SIGS = {
     "aldm_last_error": (C.c_char_p, []),
     "aldm_igemm": (C.c_int, [C.POINTER(IgemmDesc), C.c_void_p]),
     "aldm_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                  C.POINTER(C.c_int64)]),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "aldm_igemm_ws_floats": (C.c_int64, [C.POINTER(IgemmDesc)]),
+    "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_kn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

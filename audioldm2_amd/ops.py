@@ -46,23 +46,55 @@ class Packed:
 
 
 # Optional profiling hook (bench.py's roofline leg): when PROFILE is a list, every igemm launch is
-# bracketed by events on the launch stream and recorded as (what, BM, BN, flops, ev_start, ev_end).
+# bracketed by events on the launch stream and recorded as (what, BM, BN, flops, ev_start, ev_end,
+# (M, N, K, taps, C2, has_pre, pre_act, batch, splits)).
 PROFILE = None
 
 
-def _igemm(d: IgemmDesc, what: str):
+# Split-K scratch (caller-owned, see aldm_igemm_ws_floats): ONE grow-only buffer per device.  Launches
+# are stream-ordered on the current stream, so consecutive igemm calls can share it.  It grows during
+# the eager first DDIM step (every shape of the model is seen there), i.e. before graph capture.
+_ws = {}
+_ws_retired = []  # outgrown buffers stay alive: a captured HIP graph may still point at them
+
+
+def _workspace(lib, d: IgemmDesc, device) -> None:
+    need = lib.aldm_igemm_ws_floats(C.byref(d))
+    if need <= 0:
+        return
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return  # never allocate inside a capture: the launch simply runs without split-K
+        if buf is not None:
+            _ws_retired.append(buf)
+        buf = torch.empty(max(need, 8 << 20), device=device, dtype=torch.float32)
+        _ws[key] = buf
+    d.ws = buf.data_ptr()
+    d.ws_floats = buf.numel()
+
+
+def _igemm(d: IgemmDesc, what: str, device=None):
     lib = _l.load()
+    _workspace(lib, d, device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     if PROFILE is None:
         _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
         return
-    bm, bn, fl = C.c_int(), C.c_int(), C.c_int64()
-    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl)), what)
+    bm, bn, fl, sp = C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl), C.byref(sp)), what)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
     e1.record()
-    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1))
+    shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch, sp.value)
+    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape))
+
+
+def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0) -> None:
+    """Tuning override for tools/tests: force tile / split-K of subsequent igemm launches (0 = auto)."""
+    _l.load().aldm_igemm_force(bm, bn, splits)
 
 
 def _npad(n: int) -> int:
@@ -156,6 +188,10 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
     d.K = pw.K; d.N = N
     d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = out.data_ptr()
+    if rowbias is not None:
+        if not (rowbias.dim() == 2 and rowbias.stride(1) == 1 and rowbias.shape == (B, N)):
+            raise RuntimeError("conv.rowbias: need a [B, N] fp32 view with unit inner stride")
+        d.rowbias_ld = rowbias.stride(0)
     d.ldo = N; d.act = act; d.act_slope = act_slope; d.alpha = alpha
     d.accumulate = 1 if accumulate else 0
     d.out_mul = out_mul; d.out_off = out_off; d.out_len = out_len

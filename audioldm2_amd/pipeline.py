@@ -286,11 +286,12 @@ class LatentDiffusion(nn.Module):
         return self.model(x_noisy, t, cond_dict=self.reorder_cond_dict(cond))
 
     @torch.no_grad()
-    def apply_model_cfg(self, x, t2, cond, uncond):
-        """One UNet pass over [uncond ; cond] (2B samples) instead of the reference's two sequential
-        passes (ddim.py:293-296).  Contexts of different length are zero-padded to a common length
-        with mask 0 on the padding: masked scores get -FLT_MAX, whose softmax weight underflows to
-        exactly 0, so each half sees exactly its own context.  Returns eps [2, B, C, H, W]."""
+    def prepare_cfg(self, cond, uncond):
+        """Batch [uncond ; cond] conditioning ONCE per sampling run (it is step-invariant): contexts of
+        different length are zero-padded to a common length with mask 0 on the padding — masked scores
+        get -FLT_MAX, whose softmax weight underflows to exactly 0, so each half sees exactly its own
+        context.  Returning persistent tensors also lets the UNet reuse its cross-attention K/V
+        projections across the 200 steps."""
         yu, cu, mu = DiffusionWrapper.route(self.reorder_cond_dict(uncond))
         yc, cc, mc = DiffusionWrapper.route(self.reorder_cond_dict(cond))
         ctxs, masks = [], []
@@ -308,11 +309,19 @@ class LatentDiffusion(nn.Module):
             b, mb = padded(b, mb)
             ctxs.append(torch.cat([a, b], 0).contiguous())
             masks.append(torch.cat([ma, mb], 0).contiguous())
-        y = None if yc is None else torch.cat([yu, yc], 0).contiguous()
+        y = None if yc is None else torch.cat([yu, yc], 0).float().contiguous()
+        return {"ctxs": ctxs, "masks": masks, "y": y}
+
+    @torch.no_grad()
+    def apply_model_cfg(self, x, t2, cond=None, uncond=None, prepared=None):
+        """One UNet pass over [uncond ; cond] (2B samples) instead of the reference's two sequential
+        passes (ddim.py:293-296).  Returns eps [2, B, C, H, W].  `prepared` = prepare_cfg(cond, uncond)."""
+        if prepared is None:
+            prepared = self.prepare_cfg(cond, uncond)
         B = x.shape[0]
         x2 = x.repeat(2, 1, 1, 1) if x.shape[0] * 2 == t2.shape[0] else x
-        eps = self.model.diffusion_model(x2.contiguous(), t2, context_list=ctxs, y=y,
-                                         context_attn_mask_list=masks)
+        eps = self.model.diffusion_model(x2.contiguous(), t2, context_list=prepared["ctxs"], y=prepared["y"],
+                                         context_attn_mask_list=prepared["masks"])
         return eps.view(2, B, *eps.shape[1:])
 
     # -- sampling ------------------------------------------------------------------------------------------

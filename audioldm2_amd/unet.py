@@ -56,17 +56,17 @@ class ResBlock(nn.Module):
                      self.out_layers[0].bias.detach().float().cuda().contiguous()),
                 conv1=ops.pack_conv(c1.weight, c1.bias),
                 conv2=ops.pack_conv(c2.weight, c2.bias),
-                emb=ops.pack_conv(self.emb_layers[1].weight, self.emb_layers[1].bias),
                 skip=None if isinstance(self.skip_connection, nn.Identity)
                 else ops.pack_conv(self.skip_connection.weight, self.skip_connection.bias),
             )
         return self._pk
 
-    def run(self, x, emb, x2=None):
-        """x (++ x2 along C): channels-last [B, H, W, C]; emb: [B, emb_channels]."""
+    def run(self, x, e, x2=None):
+        """x (++ x2 along C): channels-last [B, H, W, C]; e: [B, out_channels] = this block's slice of
+        the batched timestep-embedding projection Linear(SiLU(emb)) (openaimodel.py:244-250, :296-298),
+        computed once per forward for all ResBlocks by UNetModel."""
         pk = self._prepare()
         sc, sh = ops.gn_stats(x, *pk["gn1"], groups=32, eps=1e-5, x2=x2)
-        e = ops.linear(emb, pk["emb"], pre_act=ACT_SILU)
         h = ops.conv(x, pk["conv1"], x2=x2, pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU, rowbias=e)
         sc2, sh2 = ops.gn_stats(h, *pk["gn2"], groups=32, eps=1e-5)
         if pk["skip"] is None:
@@ -156,6 +156,20 @@ class BasicTransformerBlock(nn.Module):
         self.heads = n_heads
         self.dim = dim
         self._pk = None
+        self._kv = None  # (context tensor, its _version, K|V projection) — see _context_kv
+
+    def _context_kv(self, context, pk):
+        """K/V projection of the cross-attention context (attention.py:336-337).  The context is the
+        same tensor for all 200 DDIM steps, so the projection is computed once and reused while the
+        SAME tensor object (unmodified: same _version) is passed again.  The cache holds a reference to
+        the context, so its storage cannot be recycled under us."""
+        c = self._kv
+        if c is not None and c[0] is context and c[1] == context._version:
+            return c[2]
+        kv = ops.linear(context, pk["kv2"])
+        if not torch.cuda.is_current_stream_capturing():  # graph-pool memory must not outlive the graph
+            self._kv = (context, context._version, kv)
+        return kv
 
     def _prepare(self):
         if self._pk is None:
@@ -192,7 +206,7 @@ class BasicTransformerBlock(nn.Module):
             a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
         else:
             q = ops.linear(n, pk["q2"])
-            kv = ops.linear(context, pk["kv2"])
+            kv = self._context_kv(context, pk)
             a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads, mask=mask)
         h = ops.linear(a, pk["out2"], res=h)
         n = ops.layernorm(h, *pk["ln"][2])
@@ -235,12 +249,13 @@ class TimestepEmbedSequential(nn.Sequential):
     first transformer of a block never gets a context, transformers beyond the list get None."""
 
     def run(self, x, emb, context_list, mask_list, x2=None):
+        """emb: dict-like indexable by a ResBlock's `_emb_slice` -> [B, out_channels] row-bias view."""
         ctxs = [None] + list(context_list)
         masks = [None] + list(mask_list)
         st_id = 0
         for layer in self:
             if isinstance(layer, ResBlock):
-                x = layer.run(x, emb, x2)
+                x = layer.run(x, emb[layer._emb_slice], x2)
                 x2 = None
             elif isinstance(layer, SpatialTransformer):
                 if st_id >= len(ctxs):
@@ -257,6 +272,16 @@ class TimestepEmbedSequential(nn.Sequential):
                 raise RuntimeError(f"unexpected layer {type(layer)}")
         assert x2 is None, "skip tensor was not consumed by a ResBlock"
         return x
+
+
+class _EmbSlices:
+    """Column-slice views of the batched timestep-embedding projection [B, sum(N)]."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __getitem__(self, sl):
+        return self.t[:, sl]
 
 
 class _ConvIn(nn.Conv2d):
@@ -359,15 +384,27 @@ class UNetModel(nn.Module):
 
     # -- packed-weight cache ---------------------------------------------------------------------
     def invalidate_packed(self):
-        """Drop every re-laid-out weight copy (call after mutating parameters)."""
+        """Drop every re-laid-out weight copy and cached context projection (call after mutating
+        parameters)."""
         for m in self.modules():
             if hasattr(m, "_pk"):
                 m._pk = None
+            if hasattr(m, "_kv"):
+                m._kv = None
 
     def _prepare(self):
         if self._pk is None:
             f = lambda t: t.detach().float().cuda().contiguous()
+            # every ResBlock's emb_layers Linear, concatenated along N: ONE [B, emb] x [emb, sum(N)] GEMM
+            # per forward instead of 22 tiny launches; block i reads columns _emb_slice
+            rbs = [m for m in self.modules() if isinstance(m, ResBlock)]
+            off = 0
+            for m in rbs:
+                m._emb_slice = slice(off, off + m.out_channels)
+                off += m.out_channels
             self._pk = dict(
+                emb_all=ops.pack_conv(torch.cat([m.emb_layers[1].weight for m in rbs], 0),
+                                      torch.cat([m.emb_layers[1].bias for m in rbs], 0)),
                 te0=ops.pack_conv(self.time_embed[0].weight, self.time_embed[0].bias),
                 te2=ops.pack_conv(self.time_embed[2].weight, self.time_embed[2].bias),
                 film=ops.pack_conv(self.film_emb.weight, self.film_emb.bias)
@@ -392,6 +429,7 @@ class UNetModel(nn.Module):
         emb = ops.linear(ops.linear(t_emb, pk["te0"], act=ACT_SILU), pk["te2"])
         if self.use_extra_film_by_concat:
             emb = torch.cat([emb, ops.linear(y.float().contiguous(), pk["film"])], dim=-1).contiguous()
+        emb = _EmbSlices(ops.linear(emb, pk["emb_all"], pre_act=ACT_SILU))
         h = ops.nchw_to_nhwc(x.float().contiguous())
         hs = []
         for module in self.input_blocks:

@@ -65,7 +65,7 @@ def roofline_probe(ld, batch, B):
     finally:
         ops.PROFILE = None
     agg = {}
-    for what, bm, bn, fl, e0, e1 in prof:
+    for what, bm, bn, fl, e0, e1, _shape in prof:
         a = agg.setdefault((bm, bn), [0, 0.0, 0.0])
         a[0] += 1
         a[1] += fl

@@ -83,7 +83,7 @@ typedef struct aldm_igemm_desc {
     /* epilogue: v = act(acc + bias[n] + rowbias[b, n]); v = alpha*(v + res[m, n]);
        out = accumulate ? out + v : v   (HiFi-GAN: xs += (resblock_j(x))/num_kernels)        */
     const float* bias;     /* [N] or NULL                                                   */
-    const float* rowbias;  /* [B, N] or NULL (timestep-embedding add, openaimodel.py:298)   */
+    const float* rowbias;  /* [B, rowbias_ld] or NULL (timestep-embedding add, openaimodel.py:298) */
     const float* res;      /* [Mout, ldo] or NULL (residual)                                */
     float* out;            /* [Mout, ldo]                                                   */
     int32_t ldo;           /* output row pitch in elements (>= N)                           */
@@ -98,12 +98,28 @@ typedef struct aldm_igemm_desc {
     /* batched GEMM: blockIdx.z = batch; element strides added per batch (0 = shared)       */
     int32_t batch;
     int64_t stride_x, stride_w, stride_o;
+    /* ABI v2 */
+    int32_t rowbias_ld;    /* row pitch of rowbias (0 => N): lets every ResBlock read its slice of
+                              ONE batched timestep-embedding projection                          */
+    int32_t reserved0;
+    float* ws;             /* optional split-K workspace (caller-owned scratch, see
+                              aldm_igemm_ws_floats); NULL or too small => no split-K            */
+    int64_t ws_floats;     /* capacity of ws in floats                                          */
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
-/* Host-only query (no launch): the block tile aldm_igemm would pick for this descriptor and the
- * algorithmic FLOPs of the call (2*M*N*K*batch) — used by bench.py's roofline accounting.      */
-int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops);
+/* Floats of split-K workspace this descriptor would use (0 = the launch fills the chip without
+ * splitting K).  Deep UNet levels have M = B*H*W of only 1024..4096 rows: their K loop is split
+ * over blockIdx.y, partial tiles go to ws and a second kernel reduces them in a fixed order and
+ * applies the epilogue (deterministic, no atomics).                                            */
+int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* d);
+/* Host-only query (no launch): the block tile / split-K factor aldm_igemm would pick for this
+ * descriptor and the algorithmic FLOPs of the call (2*M*N*K*batch) — used by bench.py's roofline
+ * accounting.  splits may be NULL.                                                              */
+int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits);
+/* Tuning override (tests / tools): force the block tile and split-K factor of subsequent
+ * aldm_igemm calls on this thread; 0 = automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
+void aldm_igemm_force(int bm, int bn, int splits);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1

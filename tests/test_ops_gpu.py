@@ -88,6 +88,77 @@ def test_conv_fused_prologue_epilogue(ops):
     assert rel_err(uncl(y), ref) < GEMM_TOL
 
 
+@pytest.mark.parametrize("bm,bn", [(128, 128), (128, 64), (64, 128), (64, 64), (128, 32)])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_igemm_every_tile_and_splitk(ops, bm, bn, splits):
+    """Every block-tile instantiation, with and without split-K (partial tiles -> workspace ->
+    deterministic reduce + epilogue), on a ragged M / ragged K-split problem with the full epilogue."""
+    B, C, N, H, W = 3, 136, 96, 13, 7  # M = 273 (ragged), K = 1224 = 38.25 k-tiles
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    b = torch.randn(N, generator=g(3))
+    emb = torch.randn(B, 2 * N, generator=g(4))
+    res = torch.randn(B, N, H, W, generator=g(5))
+    ref = F.silu(F.conv2d(x, w, b, padding=1) + emb[:, N:, None, None]) + res
+    pw = ops.pack_conv(w, b)
+    ops.igemm_force(bm, bn, splits)
+    try:
+        y1 = ops.conv(cl(x), pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res))
+        y2 = ops.conv(cl(x), pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res))
+    finally:
+        ops.igemm_force(0, 0, 0)
+    assert rel_err(uncl(y1), ref) < GEMM_TOL
+    assert torch.equal(y1, y2), "split-K reduce must be bitwise reproducible"
+
+
+def test_igemm_auto_splitk_deep_level(ops):
+    """The shape class that triggers automatic split-K (deepest UNet level: M = 1024, K = 5760) with
+    the GroupNorm+SiLU prologue, against the same launch with split-K disabled."""
+    B, C, N, H, W = 16, 640, 640, 32, 2
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    gamma, beta = torch.randn(C, generator=g(3)), torch.randn(C, generator=g(4))
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, None, padding=1)
+    a = cl(x)
+    sc, sh = ops.gn_stats(a, gamma.cuda(), beta.cuda(), groups=32, eps=1e-5)
+    pw = ops.pack_conv(w)
+    y = ops.conv(a, pw, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU)
+    assert rel_err(uncl(y), ref) < GEMM_TOL
+    ops.igemm_force(64, 64, 1)
+    try:
+        y1 = ops.conv(a, pw, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU)
+    finally:
+        ops.igemm_force(0, 0, 0)
+    assert rel_err(y, y1) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["affine", "lrelu", "silu_only", "affine_gelu"])
+def test_igemm_prologue_modes(ops, mode):
+    """Each templated operand-prologue (GN apply, leaky_relu, and the generic runtime path)."""
+    B, C, N, L = 2, 64, 48, 333
+    x = torch.randn(B, C, 1, L, generator=g(1))
+    w = torch.randn(N, C, 1, 7, generator=g(2)) / math.sqrt(C * 7)
+    sc = torch.rand(B, C, generator=g(3)) + 0.5
+    sh = torch.randn(B, C, generator=g(4))
+    aff = x * sc[:, :, None, None] + sh[:, :, None, None]
+    kw = {}
+    if mode == "affine":
+        h = aff
+        kw = dict(pre=(sc.cuda(), sh.cuda()))
+    elif mode == "lrelu":
+        h = F.leaky_relu(x, 0.1)
+        kw = dict(pre_act=ops.ACT_LRELU, pre_slope=0.1)
+    elif mode == "silu_only":
+        h = F.silu(x)
+        kw = dict(pre_act=ops.ACT_SILU)
+    else:
+        h = F.gelu(aff)
+        kw = dict(pre=(sc.cuda(), sh.cuda()), pre_act=ops.ACT_GELU)
+    ref = F.conv2d(h, w, None, padding=(0, 9), dilation=(1, 3))
+    y = ops.conv(cl(x), ops.pack_conv(w), pad=(0, 9), dil=(1, 3), **kw)
+    assert rel_err(uncl(y), ref) < GEMM_TOL
+
+
 def test_conv_upsample_nearest(ops):
     B, C, H, W = 2, 64, 8, 4
     x = torch.randn(B, C, H, W, generator=g(1))
