@@ -16,6 +16,7 @@
 
 namespace aldm {
 
+template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -29,15 +30,14 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
     const int q0 = (blockIdx.x * 4 + wave) * 32;
     if (q0 >= Lq) return;  // wave-uniform
 
-    // Q fragment: Q[q0 + l31][h*32 + 16*lh + s], pre-scaled
+    // Q fragment: Q[q0 + l31][h*32 + 16*lh + s], pre-scaled (rows past Lq are clamped, never stored)
     float qf[16];
     {
-        const int qi = q0 + l31;
+        const int qi = min(q0 + l31, Lq - 1);
         const float* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32 + 16 * lh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (qi < Lq) t = *reinterpret_cast<const f32x4*>(qp + 4 * g);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) qf[4 * g + e] = t[e] * scale;
         }
@@ -51,36 +51,36 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 
     const float* kb = k + (int64_t)b * Lk * ldk + h * 32;
     const float* vb = v + (int64_t)b * Lk * ldv + h * 32;
-    const float* mb = mask ? mask + (int64_t)b * Lk : nullptr;
+    const float* mb = HAS_MASK ? mask + (int64_t)b * Lk : nullptr;
 
-    for (int j0 = 0; j0 < Lk; j0 += 32) {
-        // K fragment (A operand): K[j0 + l31][16*lh + s]
-        float kf[16];
-        {
-            const int kj = j0 + l31;
-            const float* kp = kb + (int64_t)kj * ldk + 16 * lh;
+    // Branch-free tile loads: key indices are clamped to Lk-1 (the duplicates are masked to -inf
+    // below), so all 20 loads of a tile are issued back to back and waited for once.
+    f32x4 kraw[4];
+    float vf[16];
+    float mk[16];
+    auto load_tile = [&](int j0) {
+        const int kj = min(j0 + l31, Lk - 1);
+        const float* kp = kb + (int64_t)kj * ldk + 16 * lh;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (kj < Lk) t = *reinterpret_cast<const f32x4*>(kp + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) kf[4 * g + e] = t[e];
-            }
-        }
-        // V^T fragment (A operand of the second product): V[j0 + key(r)][dd = l31]
-        float vf[16];
+        for (int g = 0; g < 4; ++g) kraw[g] = *reinterpret_cast<const f32x4*>(kp + 4 * g);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            vf[r] = kj < Lk ? vb[(int64_t)kj * ldv + l31] : 0.f;
+            const int kr = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * lh, Lk - 1);
+            vf[r] = vb[(int64_t)kr * ldv + l31];
+            if (HAS_MASK) mk[r] = mb[kr];
         }
+    };
 
+    for (int j0 = 0; j0 < Lk; j0 += 32) {
+        load_tile(j0);
+        // S^T tile = K Q^T: lane (query l31, half lh) gets its query's scores against keys
+        // j0 + (r&3) + 8(r>>2) + 4*lh
         f32x16 st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(kraw[s >> 2][s & 3], qf[s], st, 0, 0, 0);
 
         // masking: out-of-range keys are excluded (-inf); masked keys get -FLT_MAX exactly as
         // masked_fill_(~(mask == 1), -finfo.max) does in the reference
@@ -89,18 +89,18 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         for (int r = 0; r < 16; ++r) {
             const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float sv = st[r];
-            if (kj >= Lk) sv = -INFINITY;
-            else if (mb && mb[kj] != 1.0f) sv = -FLT_MAX;
+            if (HAS_MASK) sv = mk[r] != 1.0f ? -FLT_MAX : sv;
+            sv = kj >= Lk ? -INFINITY : sv;
             st[r] = sv;
             tmax = fmaxf(tmax, sv);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
+        const float alpha = __expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = expf(st[r] - m_new);
+            const float pv = __expf(st[r] - m_new);
             st[r] = pv;
             psum += pv;
         }
@@ -144,8 +144,12 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
                  reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                "aldm_attention_d32: q/k/out must be 16-byte aligned");
     dim3 grid(cdiv(Lq, 128), heads, B);
-    hipLaunchKernelGGL(attention_d32_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out, Lq,
-                       Lk, ldq, ldk, ldv, ldo, mask, scale);
+    if (mask)
+        hipLaunchKernelGGL(attention_d32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out,
+                           Lq, Lk, ldq, ldk, ldv, ldo, mask, scale);
+    else
+        hipLaunchKernelGGL(attention_d32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out,
+                           Lq, Lk, ldq, ldk, ldv, ldo, mask, scale);
     ALDM_LAUNCH_CHECK("aldm_attention_d32");
     return 0;
 }

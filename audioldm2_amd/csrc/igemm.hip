@@ -177,45 +177,78 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     p.Kg = (d.K + 3) / 4;
     p.rb_ld = d.rowbias_ld > 0 ? d.rowbias_ld : d.N;
 
-    // ---- tile selection -------------------------------------------------------------------
-    // widest N tile the layer fills; 128-row tiles unless that grid cannot give every CU two
-    // blocks (deep UNet levels at small batch), then 64-row tiles, then split-K.
+    // ---- tile + split-K selection: a small cost model over (tile, split) candidates ------------
+    // All quantities in MFMA cycles of one SIMD.  A block alone on its 4 SIMDs needs
+    // L = kt * BM*BN/4 cycles of matrix pipe (+ per-tile staging S and a fixed prologue/epilogue F);
+    // `occ` co-resident blocks share the pipe.  Blocks go round-robin over the 256 CUs; the last,
+    // partially filled round costs as much as its fullest CU.  Split-K adds a reduce pass.
     const int nk = (d.K + BK - 1) / BK;
+    const int64_t Mz = p.M;
+    // Constants fitted on MI355X to a (tile x split) sweep over the UNet's shapes (tools/igemm_tune.py,
+    // profiles/r01_igemm_tune.txt): S = un-overlapped staging cycles per k-tile (per 32 A rows / B
+    // columns; x1.5 with a GroupNorm/SiLU prologue), F = fixed block prologue + epilogue, reduce =
+    // 10k cycles + (splits + 1) * M * N * 4 B at 2000 B/cycle.
+    auto occ_of = [](int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : ((bm * bn >= 64 * 128 || bn == 32) ? 3 : 4); };
+    const double pre_w = (d.pre_scale != nullptr || d.pre_act != ALDM_ACT_NONE) ? 1.5 : 1.0;
+    auto cost_of = [&](int bm, int bn, int sp, int* sp_eff) -> double {
+        const int kt = cdiv(nk, sp);
+        sp = cdiv(nk, kt);
+        *sp_eff = sp;
+        const double blocks = (double)cdiv64(Mz, bm) * cdiv(d.N, bn) * d.batch * sp;
+        const double L = (double)kt * bm * bn / 4.0;
+        const int o = occ_of(bm, bn);
+        const double S = 300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32), F = 4000.0;
+        const int64_t nb = (int64_t)((blocks + 255.0) / 256.0);
+        const int64_t full = nb / o, last = nb - full * o;
+        const double one = L + kt * S + F;
+        double T = full * std::max(one, o * L);
+        if (last) T += std::max(one, last * L);
+        if (sp > 1) T += 10000.0 + (double)(sp + 1) * Mz * d.N * d.batch * 4.0 / 2000.0;
+        return T;
+    };
+    const bool can_split = d.N % 4 == 0 && nk >= 8;
+    const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
+    int splits = 1;
     if (g_force_bm) {
         BM = g_force_bm;
         BN = g_force_bn;
         ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm_force: unsupported tile %dx%d", BM, BN);
-    } else {
-        BN = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+        if (g_force_splits > 0 && can_split) splits = g_force_splits;
+    } else if (d.N <= 32) {
         BM = 128;
-        if (BN >= 64) {
-            const int64_t blocks128 = cdiv64(p.M, 128) * cdiv(d.N, BN) * d.batch;
-            if (blocks128 < 512) BM = 64;
-        }
-        if (BM == 64 && BN == 128) {
-            const int64_t blocks = cdiv64(p.M, 64) * cdiv(d.N, 128) * d.batch;
-            if (blocks < 256 && d.N % 64 == 0) BN = 64;
+        BN = 32;
+    } else {
+        static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+        static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+        double best = 1e300;
+        BM = 64;
+        BN = 64;
+        for (int c = 0; c < 4; ++c) {
+            const int bm = cand[c][0], bn = cand[c][1];
+            if (bn > 64 && d.N <= 64) continue;
+            for (int si = 0; si < 8; ++si) {
+                const int sp = sps[si];
+                if (sp > 1 && (!can_split || !have_ws || nk / sp < 3)) break;
+                int spe;
+                const double t = cost_of(bm, bn, sp, &spe);
+                if (spe > 1 && (int64_t)d.batch * spe * Mz * d.N > d.ws_floats) continue;
+                if (t < best) {
+                    best = t;
+                    BM = bm;
+                    BN = bn;
+                    splits = spe;
+                }
+            }
         }
     }
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(d.N, BN);
-    // ---- split-K ----------------------------------------------------------------------------
-    int splits = 1;
-    const int64_t blocks = (int64_t)p.tiles_m * p.tiles_n * d.batch;
-    const bool can_split = d.N % 4 == 0 && nk >= 8;
-    if (g_force_splits > 0) {
-        splits = can_split ? g_force_splits : 1;
-    } else if (can_split && blocks < 384) {
-        const int want = (BM == 64 && BN == 64) ? 1024 : 512;  // resident blocks the chip can hold
-        splits = (int)std::min<int64_t>(cdiv64(want, blocks), 16);
-        splits = std::min(splits, nk / 4);  // >= 4 k-tiles per split
-    }
     if (splits < 1) splits = 1;
     p.kt_per_split = cdiv(nk, splits);
     splits = cdiv(nk, p.kt_per_split);  // no empty split
     if (splits > 1) {
         const int64_t need = (int64_t)d.batch * splits * p.M * d.N;
-        if (d.ws == nullptr || d.ws_floats < need || (reinterpret_cast<uintptr_t>(d.ws) & 15)) {
+        if (!have_ws || d.ws_floats < need) {
             splits = 1;
             p.kt_per_split = nk;
         }

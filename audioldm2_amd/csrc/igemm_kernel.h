@@ -60,15 +60,24 @@ __device__ __forceinline__ float silu_fast(float v) {
     return v * __frcp_rn(1.0f + __expf(-v));
 }
 
+// resident blocks per CU the register budget must allow (LDS allows 2 / 3 / 4 for the three tile sizes)
+constexpr int igemm_min_blocks(int BM, int BN) {
+    return BM * BN >= 128 * 128 ? 2 : ((BM * BN >= 64 * 128 || BN == 32) ? 3 : 4);
+}
+
 template <int BM, int BN, int WM, int WN, int PRE>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
+__global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(const IgemmK p) {
     constexpr int MT = BM / (32 * WM);
     constexpr int NT = BN / (32 * WN);
     constexpr int PA = BM / 32;  // A-loader passes (32 rows x 8 k-groups per pass)
     constexpr int PB = BN / 32;  // B-loader passes
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ f32x4 As[2][KG][BM + 1];
-    __shared__ f32x4 Bs[2][KG][BN + 1];
+    // one raw LDS buffer: A/B double buffers during the K loop, per-wave output staging afterwards
+    constexpr int A_F4 = 2 * KG * (BM + 1);
+    constexpr int B_F4 = 2 * KG * (BN + 1);
+    __shared__ f32x4 smem[A_F4 + B_F4];
+    f32x4 (*As)[KG][BM + 1] = reinterpret_cast<f32x4 (*)[KG][BM + 1]>(&smem[0]);
+    f32x4 (*Bs)[KG][BN + 1] = reinterpret_cast<f32x4 (*)[KG][BN + 1]>(&smem[A_F4]);
 
     const aldm_igemm_desc& d = p.d;
     const int tid = threadIdx.x;
@@ -132,12 +141,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
     }
     const int pix1 = d.pix1, pix2 = d.pix2;
 
-    // ---- B loader bookkeeping ----
-    // PACKED: thread -> column n = tid % BN, k-groups kgb0 + stepb*pp ; NT: row r0 + 32*pp, k-group tid & 7
+    // ---- B loader bookkeeping (branch-free over both layouts) ----
+    // load pp of k-tile kt reads offset kt*b_kt + pp*b_pp + b_base; it is valid iff
+    //   kt*b_ks + pp*b_kps + b_k0 < b_klim  and  pp*b_nps + b_n0 < b_nlim ;
+    // it is stored at Bs[buf][b_skg + pp*b_skgs][b_sc + pp*b_scs].
+    //   PACKED [Kg][Npad][4]: thread -> column tid % BN, k-groups tid / BN + (256/BN)*pp
+    //   NT     Bmat[N][ldb] : thread -> row tid / 8 + 32*pp, k-group tid % 8
     constexpr int stepb = 256 / BN;
     const bool packed = d.b_mode == ALDM_B_PACKED;
-    const int bn_col = tid % BN;
-    const int bkg0 = tid / BN;
+    const int64_t b_kt = packed ? (int64_t)KG * p.Npad * 4 : BK;
+    const int64_t b_pp = packed ? (int64_t)stepb * p.Npad * 4 : (int64_t)32 * d.ldb;
+    const int64_t b_base = packed ? ((int64_t)(tid / BN) * p.Npad + n0 + tid % BN) * 4
+                                  : (int64_t)(n0 + ar0) * d.ldb + 4 * akg;
+    const int b_ks = packed ? KG : BK, b_kps = packed ? stepb : 0;
+    const int b_k0 = packed ? tid / BN : 4 * akg, b_klim = packed ? p.Kg : d.K;
+    const int b_nps = packed ? 0 : 32, b_n0 = packed ? n0 + tid % BN : n0 + ar0;
+    const int b_nlim = packed ? p.Npad : d.N;
+    const int b_skg = packed ? tid / BN : akg, b_skgs = packed ? stepb : 0;
+    const int b_sc = packed ? tid % BN : ar0, b_scs = packed ? 0 : 32;
 
     f32x4 ra[PA], rb[PB];
     f32x4 rsc[(PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) ? PA : 1];
@@ -182,25 +203,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
         }
         // ---- B ----
         bvalid = 0;
-        if (packed) {
 #pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                const int kg = kt * KG + bkg0 + stepb * pp;
-                const bool ok = kg < p.Kg && n0 + bn_col < p.Npad;
-                const int64_t off = ok ? ((int64_t)kg * p.Npad + n0 + bn_col) * 4 : 0;
-                rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
-                bvalid |= (ok ? 1u : 0u) << pp;
-            }
-        } else {  // NT: Bmat[N][ldb]
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                const int n = n0 + ar0 + 32 * pp;
-                const int k = kt * BK + 4 * akg;
-                const bool ok = n < d.N && k < d.K;
-                const int64_t off = ok ? (int64_t)n * d.ldb + k : 0;
-                rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
-                bvalid |= (ok ? 1u : 0u) << pp;
-            }
+        for (int pp = 0; pp < PB; ++pp) {
+            const bool ok = kt * b_ks + pp * b_kps + b_k0 < b_klim && pp * b_nps + b_n0 < b_nlim;
+            const int64_t off = ok ? kt * b_kt + pp * b_pp + b_base : 0;
+            rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
+            bvalid |= (ok ? 1u : 0u) << pp;
         }
     };
 
@@ -228,20 +236,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
             if (!((avalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
             As[buf][akg][ar0 + 32 * pp] = v;
         }
-        if (packed) {
 #pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                f32x4 v = rb[pp];
-                if (!((bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                Bs[buf][bkg0 + stepb * pp][bn_col] = v;
-            }
-        } else {
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                f32x4 v = rb[pp];
-                if (!((bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                Bs[buf][akg][ar0 + 32 * pp] = v;
-            }
+        for (int pp = 0; pp < PB; ++pp) {
+            f32x4 v = rb[pp];
+            if (!((bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            Bs[buf][b_skg + pp * b_skgs][b_sc + pp * b_scs] = v;
         }
     };
 
@@ -284,7 +283,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
         for (int kt = kt0; kt + 1 < kt1; ++kt) {
             issue_loads(kt + 1);
             mma_half(buf, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use (commit) behind half the MFMAs
             commit(buf ^ 1);
             mma_half(buf, 1);
             __syncthreads();
@@ -294,56 +293,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
         mma_half(buf, 1);
     }
 
-    // ---- epilogue ----
-    if (p.splits > 1) {
-        // raw partial tile -> workspace [z][split][M][N]
-        float* wsp = d.ws + ((int64_t)z * p.splits + split) * (int64_t)p.M * d.N;
+    // ---- epilogue ------------------------------------------------------------------------------
+    // The MFMA accumulator layout gives a lane 4-byte pieces of 16 different rows; storing those
+    // directly is store-issue bound (one dword store instruction per element).  Instead each wave
+    // transposes its 32 x (NT*32) slab through its private LDS region and every lane then owns
+    // float4s along N: bias / residual / previous-output loads and the stores are 16 bytes wide,
+    // all optional operands are fetched with unconditional loads from clamped addresses.
+    //   v = act(acc + bias + rowbias); v = alpha*(v + res); out = accumulate ? out + v : v
+    constexpr int SP = NT * 32 + 4;   // staging row pitch (floats); +4 keeps 16-byte alignment
+    constexpr int C4 = NT * 8;        // float4 per staged row
+    constexpr int RPI = 64 / C4;      // rows covered by one wave-wide float4 read
+    constexpr int IT = 32 / RPI;      // reads per 32-row slab
+    static_assert(4 * 32 * SP * 4 <= (A_F4 + B_F4) * 16, "staging must fit the K-loop LDS");
+    __syncthreads();  // every wave is done reading As/Bs
+    float* stg = reinterpret_cast<float*>(&smem[0]) + wave * (32 * SP);
+    const int sr = lane / C4;          // row within an RPI group
+    const int sc = (lane % C4) * 4;    // column within the wave's slab
+    const int ncol = n0 + wn * NT * 32 + sc;
+    const bool split_out = p.splits > 1;
+    const bool vec = split_out || ((d.ldo & 3) == 0 && (d.N & 3) == 0 &&
+                                   ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res)) & 15) == 0 &&
+                                   ((d.stride_o & 3) == 0));
+    float* outp = split_out ? d.ws + ((int64_t)z * p.splits + split) * (int64_t)p.M * d.N
+                            : d.out + (int64_t)z * d.stride_o;
+    const float* resp = (!split_out && d.res) ? d.res + (int64_t)z * d.stride_o : nullptr;
+    const bool need_b = !split_out && (d.rowbias != nullptr || d.out_mul > 0);
+    const int ld_out = split_out ? d.N : d.ldo;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (!split_out && d.bias) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = n0 + (wn * NT + j) * 32 + l31;
-                    if (n < d.N) wsp[(int64_t)m * d.N + n] = acc[i][j][e];
-                }
-            }
-        return;
-    }
-    // Fused epilogue, restructured for memory-level parallelism: per 32-row slab all row offsets are
-    // computed first, then every optional operand (row bias, residual, previous output) is fetched
-    // with unconditional loads from clamped addresses (no branch + wait per element), then the math,
-    // then the stores.  v = act(acc + bias + rowbias); v = alpha*(v + res); out = acc ? out + v : v
-    float* outp = d.out + (int64_t)z * d.stride_o;
-    const float* resp = d.res ? d.res + (int64_t)z * d.stride_o : nullptr;
-    const bool need_b = d.rowbias != nullptr || d.out_mul > 0;
-    int ncl[NT];
-    bool nok[NT];
-    float biasv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + (wn * NT + j) * 32 + l31;
-        nok[j] = n < d.N;
-        ncl[j] = nok[j] ? n : 0;
-        biasv[j] = 0.f;
-    }
-    if (d.bias) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) biasv[j] = d.bias[ncl[j]];
+        for (int c = 0; c < 4; ++c) bias4[c] = d.bias[min(ncol + c, d.N - 1)];
     }
 #pragma unroll
-    for (int ih = 0; ih < 2 * MT; ++ih) {  // 16-row half slabs: 8 accumulator rows per lane
-        const int i = ih >> 1, e0 = (ih & 1) * 8;
-        int64_t rowoff[8];
-        int rboff[8];
+    for (int i = 0; i < MT; ++i) {
+        // registers -> LDS (wave private, conflict free: 32 consecutive columns per half wave)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][e];
+        // LDS -> float4 per lane
+        f32x4 v[IT];
+        int64_t rowoff[IT];
+        int rboff[IT];
         unsigned okmask = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ee = e0 + e;
-            const int m = m0 + (wm * MT + i) * 32 + (ee & 3) + 8 * (ee >> 2) + 4 * lh;
-            bool ok = m < p.M;
+        for (int it = 0; it < IT; ++it) {
+            const int r = it * RPI + sr;
+            v[it] = *reinterpret_cast<const f32x4*>(&stg[r * SP + sc]);
+            const int m = m0 + (wm * MT + i) * 32 + r;
+            bool ok = m < p.M && ncol < d.N;
             int b = 0;
             int64_t orow = m;
             if (need_b) {
@@ -355,63 +354,72 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK p) {
                     orow = (int64_t)b * d.out_len + t;
                 }
             }
-            rowoff[e] = ok ? orow * d.ldo : 0;
-            rboff[e] = ok ? b * p.rb_ld : 0;
-            okmask |= (ok ? 1u : 0u) << e;
+            rowoff[it] = ok ? orow * ld_out + ncol : 0;
+            rboff[it] = ok ? b * p.rb_ld + ncol : 0;
+            okmask |= (ok ? 1u : 0u) << it;
         }
-        float v[8][NT];
+        if (split_out) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+            for (int it = 0; it < IT; ++it)
+                if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
+            continue;
+        }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) v[e][j] = acc[i][j][e0 + e] + biasv[j];
+        for (int it = 0; it < IT; ++it) v[it] += bias4;
         if (d.rowbias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+            for (int it = 0; it < IT; ++it)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) v[e][j] += d.rowbias[rboff[e] + ncl[j]];
+                for (int c = 0; c < 4; ++c) v[it][c] += d.rowbias[rboff[it] + (ncol + c < d.N ? c : 0)];
         }
         switch (d.act) {
             case ALDM_ACT_NONE: break;
             case ALDM_ACT_SILU:
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
+                for (int it = 0; it < IT; ++it)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) v[e][j] = act_apply(v[e][j], ALDM_ACT_SILU, 0.f);
+                    for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], ALDM_ACT_SILU, 0.f);
                 break;
             case ALDM_ACT_GELU:
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
+                for (int it = 0; it < IT; ++it)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) v[e][j] = act_apply(v[e][j], ALDM_ACT_GELU, 0.f);
+                    for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], ALDM_ACT_GELU, 0.f);
                 break;
             default:
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
+                for (int it = 0; it < IT; ++it)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) v[e][j] = act_apply(v[e][j], d.act, d.act_slope);
+                    for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], d.act, d.act_slope);
                 break;
         }
-        if (resp) {
+        if (vec) {
+            if (resp) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+                for (int it = 0; it < IT; ++it) v[it] += *reinterpret_cast<const f32x4*>(resp + rowoff[it]);
+            }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) v[e][j] += resp[rowoff[e] + ncl[j]];
+            for (int it = 0; it < IT; ++it) v[it] *= d.alpha;
+            if (d.accumulate) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) v[it] += *reinterpret_cast<const f32x4*>(outp + rowoff[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+                if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
+        } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (!((okmask >> it) & 1u) || ncol + c >= d.N) continue;
+                    float x = v[it][c];
+                    if (resp) x += resp[rowoff[it] + c];
+                    x *= d.alpha;
+                    if (d.accumulate) x += outp[rowoff[it] + c];
+                    outp[rowoff[it] + c] = x;
+                }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) v[e][j] *= d.alpha;
-        if (d.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) v[e][j] += outp[rowoff[e] + ncl[j]];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                if (((okmask >> e) & 1u) && nok[j]) outp[rowoff[e] + ncl[j]] = v[e][j];
     }
 }
 

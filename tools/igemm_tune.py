@@ -48,6 +48,9 @@ def sweep(name, fn, flops, M, N, nk):
             finally:
                 ops.igemm_force(0, 0, 0)
             res.append((t, bm, bn, sp, blocks))
+    for t, bm, bn, sp, blocks in res:
+        print(f"CSV,{name},{M},{N},{nk},{bm},{bn},{sp},{t*1e6:.1f}")
+    print(f"CSV,{name},{M},{N},{nk},0,0,0,{t_auto*1e6:.1f}")
     res.sort()
     best = res[0]
     line = "  ".join(f"{bm}x{bn}/s{sp}:{t*1e6:.0f}us" for t, bm, bn, sp, _ in res[:5])
