@@ -144,7 +144,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.pix1 % 4 == 0 && d.pix2 % 4 == 0, "aldm_igemm: pixel pitch must be a multiple of 4");
     ALDM_CHECK(d.K == d.KH * d.KW * p.Cin, "aldm_igemm: K=%d != KH*KW*Cin=%d", d.K,
                d.KH * d.KW * p.Cin);
-    ALDM_CHECK(d.N > 0 && d.ldo >= d.N, "aldm_igemm: bad N=%d ldo=%d", d.N, d.ldo);
+    ALDM_CHECK(d.N > 0 && (d.ldo >= d.N || d.epi_mode == ALDM_EPI_GEGLU), "aldm_igemm: bad N=%d ldo=%d", d.N, d.ldo);
     ALDM_CHECK(d.B > 0 && d.H > 0 && d.W > 0 && d.OH > 0 && d.OW > 0, "aldm_igemm: bad extents");
     ALDM_CHECK(d.SH > 0 && d.SW > 0 && d.DH > 0 && d.DW > 0, "aldm_igemm: bad stride/dilation");
     p.shh = log2_exact(d.up_h);
@@ -167,6 +167,15 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.pre_scale == nullptr ||
                    ((reinterpret_cast<uintptr_t>(d.pre_scale) | reinterpret_cast<uintptr_t>(d.pre_shift)) & 15) == 0,
                "aldm_igemm: pre_scale/pre_shift must be 16-byte aligned");
+    const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
+    ALDM_CHECK(d.epi_mode == ALDM_EPI_PLAIN || geglu, "aldm_igemm: unknown epi_mode %d", d.epi_mode);
+    if (geglu) {
+        ALDM_CHECK(d.N % 64 == 0 && d.ldo >= d.N / 2 && d.ldo % 4 == 0 && d.b_mode == ALDM_B_PACKED &&
+                       d.out_mul == 0 && !d.res && !d.rowbias && !d.accumulate && d.act == ALDM_ACT_NONE &&
+                       (reinterpret_cast<uintptr_t>(d.out) & 15) == 0 && d.stride_o % 4 == 0 &&
+                       (d.bias == nullptr || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0),
+                   "aldm_igemm: GEGLU epilogue needs N %% 64 == 0, ldo >= N/2, packed weights, a plain epilogue");
+    }
     p.OHW = d.OH * d.OW;
     const int64_t M64 = (int64_t)d.B * p.OHW;
     ALDM_CHECK(M64 < (1ll << 31) - 256, "aldm_igemm: M too large");
@@ -206,15 +215,16 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         if (sp > 1) T += 10000.0 + (double)(sp + 1) * Mz * d.N * d.batch * 4.0 / 2000.0;
         return T;
     };
-    const bool can_split = d.N % 4 == 0 && nk >= 8;
+    const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu;
     const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
     int splits = 1;
     if (g_force_bm) {
         BM = g_force_bm;
         BN = g_force_bn;
         ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm_force: unsupported tile %dx%d", BM, BN);
+        ALDM_CHECK(!geglu || BN == 128, "aldm_igemm_force: the GEGLU epilogue needs a 128-column tile");
         if (g_force_splits > 0 && can_split) splits = g_force_splits;
-    } else if (d.N <= 32) {
+    } else if (d.N <= 32 && !geglu) {
         BM = 128;
         BN = 32;
     } else {
@@ -225,7 +235,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         BN = 64;
         for (int c = 0; c < 4; ++c) {
             const int bm = cand[c][0], bn = cand[c][1];
-            if (bn > 64 && d.N <= 64) continue;
+            if (geglu ? bn != 128 : (bn > 64 && d.N <= 64)) continue;  // 
             for (int si = 0; si < 8; ++si) {
                 const int sp = sps[si];
                 if (sp > 1 && (!can_split || !have_ws || nk / sp < 3)) break;
@@ -241,6 +251,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             }
         }
     }
+    ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: internal: GEGLU epilogue without a 128-column tile");
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(d.N, BN);
     if (splits < 1) splits = 1;

@@ -319,6 +319,41 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     const float* resp = (!split_out && d.res) ? d.res + (int64_t)z * d.stride_o : nullptr;
     const bool need_b = !split_out && (d.rowbias != nullptr || d.out_mul > 0);
     const int ld_out = split_out ? d.N : d.ldo;
+    if constexpr (NT == 2) {
+        if (d.epi_mode == ALDM_EPI_GEGLU) {
+            // fused GEGLU (attention.py:42-44): the wave's slab holds 32 value columns then their 32
+            // gate columns; 8 lanes cover a row's 32 outputs, one wave-wide read covers 8 rows.
+            const int gr = lane >> 3, gc = (lane & 7) * 4;
+            const int ncol_p = n0 + wn * 64 + gc;              // packed column of the value quad
+            const int ncol_o = ((n0 + wn * 64) >> 1) + gc;     // output column
+            const bool cok = ncol_p < d.N;  // N % 64 == 0: a wave's 64-column slab is all in or all out
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias && cok) {
+                bv = *reinterpret_cast<const f32x4*>(d.bias + ncol_p);
+                bg = *reinterpret_cast<const f32x4*>(d.bias + ncol_p + 32);
+            }
+            float* go = d.out + (int64_t)z * d.stride_o;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][e];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + gr;
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(&stg[r * SP + gc]) + bv;
+                    const f32x4 xg = *reinterpret_cast<const f32x4*>(&stg[r * SP + 32 + gc]) + bg;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] *= act_apply(xg[c], ALDM_ACT_GELU, 0.f);
+                    const int m = m0 + (wm * MT + i) * 32 + r;
+                    if (m < p.M && cok) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;
+                }
+            }
+            return;
+        }
+    }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (!split_out && d.bias) {
 #pragma unroll

@@ -44,6 +44,56 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     return torch.as_tensor(np.asarray(sigmas, dtype=np.float64)), alphas, alphas_prev
 
 
+class _NoiseFeed:
+    """Streams the per-step host noise to the GPU in chunks, overlapping the CPU generator (the
+    reference's RNG stream, drawn strictly in its order) and the PCIe upload with the UNet steps of the
+    previous chunk: chunk c+1 is drawn and uploaded on a side stream while the GPU runs chunk c.
+    Device buffers hold all steps; `wait(i)` makes the current stream wait for step i's chunk."""
+
+    def __init__(self, draw, steps, shape, with_mask, temperature, dev, chunk=8):
+        self.draw, self.steps, self.with_mask, self.temperature = draw, steps, with_mask, temperature
+        self.chunk = chunk
+        self.noise = torch.empty((steps,) + tuple(shape), device=dev, dtype=torch.float32)
+        self.qnoise = torch.empty_like(self.noise) if with_mask else None
+        nbuf = 2
+        self.pin = [torch.empty((chunk,) + tuple(shape)).pin_memory() for _ in range(nbuf)]
+        self.qpin = [torch.empty((chunk,) + tuple(shape)).pin_memory() for _ in range(nbuf)] if with_mask else None
+        self.stream = torch.cuda.Stream(device=dev)
+        self.events = {}
+        self.produced = 0  # chunks drawn so far
+
+    def produce_next(self):
+        c = self.produced
+        lo = c * self.chunk
+        if lo >= self.steps:
+            return
+        hi = min(self.steps, lo + self.chunk)
+        slot = c % len(self.pin)
+        prev = self.events.get(c - len(self.pin))
+        if prev is not None:
+            prev.synchronize()  # the upload that last used this pinned slot is done
+        for s in range(lo, hi):  # reference order per step: [q_sample noise], step noise
+            if self.with_mask:
+                self.qpin[slot][s - lo].copy_(self.draw())
+            n = self.draw()
+            self.pin[slot][s - lo].copy_(n * self.temperature if self.temperature != 1.0 else n)
+        with torch.cuda.stream(self.stream):
+            self.noise[lo:hi].copy_(self.pin[slot][:hi - lo], non_blocking=True)
+            if self.with_mask:
+                self.qnoise[lo:hi].copy_(self.qpin[slot][:hi - lo], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.events[c] = ev
+        self.produced = c + 1
+
+    def wait(self, i):
+        c = i // self.chunk
+        while self.produced <= c:
+            self.produce_next()
+        if i % self.chunk == 0:
+            torch.cuda.current_stream().wait_event(self.events[c])
+
+
 class DDIMSampler(object):
     def __init__(self, model, schedule="linear", device=torch.device("cuda"), **kwargs):
         super().__init__()
@@ -102,16 +152,20 @@ class DDIMSampler(object):
                                   unconditional_conditioning=unconditional_conditioning)
 
     # ------------------------------------------------------------------------------------------
+    def _drawer(self, shape):
+        """One reference-ordered Gaussian draw from the HOST default generator (RNG contract R)."""
+        if self.noise_shard is None:
+            return lambda: torch.randn(shape)
+        # prompt-sharded run: draw the GLOBAL batch like the single-process reference, keep our rows
+        gB, off = self.noise_shard
+        gshape = (gB,) + tuple(shape[1:])
+        return lambda: torch.randn(gshape)[off:off + shape[0]].contiguous()
+
     def _draw_noise(self, shape, steps, x_T, with_mask):
         """Replays the reference's host RNG order: x_T, then per step [q_sample noise (inpainting
-        only, ddim.py:228 / ddpm.py:430-436)], step noise (ddim.py:351)."""
-        if self.noise_shard is None:
-            draw = lambda: torch.randn(shape)
-        else:
-            # prompt-sharded run: draw the GLOBAL batch like the single-process reference, keep our rows
-            gB, off = self.noise_shard
-            gshape = (gB,) + tuple(shape[1:])
-            draw = lambda: torch.randn(gshape)[off:off + shape[0]].contiguous()
+        only, ddim.py:228 / ddpm.py:430-436)], step noise (ddim.py:351).  (Eager form, used by tests;
+        ddim_sampling streams the same sequence through _NoiseFeed.)"""
+        draw = self._drawer(shape)
         img = draw() if x_T is None else x_T
         step_noise, q_noise = [], []
         for _ in range(steps):
@@ -136,10 +190,14 @@ class DDIMSampler(object):
         time_range = np.flip(ts)
         use_cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
 
-        x_host = None if x_T is None else x_T.detach().float().cpu()
-        img_h, noise_h, qnoise_h = self._draw_noise(tuple(shape), total_steps, x_host, mask is not None)
+        # RNG contract R: x_T first, then the per-step draws, all from the host generator in the
+        # reference's order; the per-step draws are streamed (see _NoiseFeed)
+        draw = self._drawer(tuple(shape))
+        img_h = draw() if x_T is None else x_T.detach().float().cpu()
         img = img_h.to(dev).contiguous()
-        noise = (noise_h * temperature).to(dev) if temperature != 1.0 else noise_h.to(dev)
+        feed = _NoiseFeed(draw, total_steps, tuple(shape), mask is not None, temperature, dev)
+        feed.produce_next()
+        noise, qn = feed.noise, feed.qnoise
         # device tables in loop order (i = 0 is the noisiest step, index = total_steps - 1)
         order = [total_steps - i - 1 for i in range(total_steps)]
         coef = torch.zeros(total_steps, 8)
@@ -154,7 +212,6 @@ class DDIMSampler(object):
             assert x0 is not None
             mask_d = mask.float().to(dev).expand(shape).contiguous()
             x0_d = x0.float().to(dev).contiguous()
-            qn = qnoise_h.to(dev)
             sa = self.sqrt_alphas_cumprod[torch.from_numpy(np.ascontiguousarray(time_range - 0))].to(dev)
             so = self.sqrt_one_minus_alphas_cumprod[torch.from_numpy(np.ascontiguousarray(time_range - 0))].to(dev)
 
@@ -164,7 +221,7 @@ class DDIMSampler(object):
         pred_x0 = torch.empty_like(x_cur)
         t_cur = t_tab[0].clone()
         coef_cur = coef[0].clone()
-        noise_cur = noise[0].clone()
+        noise_cur = torch.empty_like(x_cur)
 
         cfg_fused = use_cfg and hasattr(self.model, "apply_model_cfg")
         prepared = self.model.prepare_cfg(cond, unconditional_conditioning) \
@@ -189,6 +246,7 @@ class DDIMSampler(object):
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         for i, step_t in enumerate(time_range):
             index = total_steps - i - 1
+            feed.wait(i)  # current stream waits for the upload of step i's noise chunk
             t_cur.copy_(t_tab[i])
             coef_cur.copy_(coef[i])
             noise_cur.copy_(noise[i])
@@ -205,6 +263,8 @@ class DDIMSampler(object):
                 graph.replay()
             else:
                 step()  # first step runs eagerly: packs weights, warms the allocator
+            if i % feed.chunk == 0:
+                feed.produce_next()  # draw + upload the NEXT chunk while the GPU works on this one
             if callback:
                 callback(i)
             if img_callback:

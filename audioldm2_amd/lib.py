@@ -15,6 +15,7 @@ ABI_VERSION = 2
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
 B_PACKED, B_NT = 0, 1
+EPI_PLAIN, EPI_GEGLU = 0, 1
 
 
 class IgemmDesc(C.Structure):
@@ -40,7 +41,7 @@ class IgemmDesc(C.Structure):
         ("out_mul", C.c_int32), ("out_off", C.c_int32), ("out_len", C.c_int32),
         ("batch", C.c_int32),
         ("stride_x", C.c_int64), ("stride_w", C.c_int64), ("stride_o", C.c_int64),
-        ("rowbias_ld", C.c_int32), ("reserved0", C.c_int32),
+        ("rowbias_ld", C.c_int32), ("epi_mode", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 

@@ -119,6 +119,39 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> Pack
     return Packed(dst, N, Cin, KH, KW, b)
 
 
+def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
+    """GEGLU projection Linear(dim, 2*inner) (attention.py:40): rows [0, inner) are the value half, rows
+    [inner, 2*inner) the gate half (`x, gate = proj(x).chunk(2, -1)`).  Re-order the output channels into
+    groups of 32 value rows followed by their 32 gate rows so one MFMA wave holds both (EPI_GEGLU)."""
+    two_inner = weight.shape[0]
+    inner = two_inner // 2
+    assert weight.dim() == 2 and two_inner % 64 == 0
+    g = torch.arange(inner // 32).view(-1, 1, 1)
+    j = torch.arange(2).view(1, -1, 1)
+    l = torch.arange(32).view(1, 1, -1)
+    perm = (j * inner + g * 32 + l).reshape(-1).to(weight.device)
+    return pack_conv(weight.detach()[perm], None if bias is None else bias.detach()[perm])
+
+
+def linear_geglu(x: torch.Tensor, pw: Packed) -> torch.Tensor:
+    """y = value * gelu_erf(gate) with [value | gate] = x @ W^T + b fused into the GEMM epilogue
+    (attention.py:37-45); pw from pack_geglu.  x: [..., Cin] -> [..., N/2]."""
+    _chk(x, "linear_geglu.x")
+    shp = x.shape
+    M = x.numel() // shp[-1]
+    assert shp[-1] == pw.Cin and pw.KH == 1 and pw.KW == 1 and pw.N % 64 == 0
+    out = torch.empty((*shp[:-1], pw.N // 2), device=x.device, dtype=torch.float32)
+    d = IgemmDesc()
+    d.x1 = x.data_ptr(); d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
+    d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
+    d.OH = 1; d.OW = M
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
+    d.bias = _p(pw.bias); d.out = out.data_ptr(); d.ldo = pw.N // 2; d.alpha = 1.0
+    d.epi_mode = _l.EPI_GEGLU; d.batch = 1
+    _igemm(d, "igemm(geglu)")
+    return out
+
+
 def pack_convtr1d(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int) -> List[Packed]:
     """ConvTranspose1d weight [Cin, N, K] -> one Packed per output phase (polyphase decomposition)."""
     w = weight.detach().to(device="cuda", dtype=torch.float32).contiguous()

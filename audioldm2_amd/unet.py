@@ -185,7 +185,7 @@ class BasicTransformerBlock(nn.Module):
                 q2=ops.pack_conv(a2.to_q.weight),
                 kv2=ops.pack_conv(torch.cat([a2.to_k.weight, a2.to_v.weight], 0)),
                 out2=ops.pack_conv(a2.to_out[0].weight, a2.to_out[0].bias),
-                ff1=ops.pack_conv(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias),
+                ff1=ops.pack_geglu(self.ff.net[0].proj.weight, self.ff.net[0].proj.bias),
                 ff2=ops.pack_conv(self.ff.net[2].weight, self.ff.net[2].bias),
             )
         return self._pk
@@ -210,7 +210,7 @@ class BasicTransformerBlock(nn.Module):
             a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads, mask=mask)
         h = ops.linear(a, pk["out2"], res=h)
         n = ops.layernorm(h, *pk["ln"][2])
-        g = ops.geglu(ops.linear(n, pk["ff1"]))
+        g = ops.linear_geglu(n, pk["ff1"])  # Linear(C, 8C) + x*gelu(gate) in one GEMM (attention.py:37-45)
         return ops.linear(g, pk["ff2"], res=h)
 
 

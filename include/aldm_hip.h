@@ -40,6 +40,14 @@ enum {
     ALDM_ACT_GELU = 5       /* exact erf GELU: attention.py:44                              */
 };
 
+/* epilogue modes of aldm_igemm.
+ * ALDM_EPI_GEGLU: the GEMM computes the 2*C-wide GEGLU projection, but only C columns are
+ * stored: out[m, g*32 + l] = (acc[m, g*64 + l] + bias) * gelu_erf(acc[m, g*64 + 32 + l] + bias),
+ * i.e. the weight's output channels are interleaved in groups of 32 (value block, gate block)
+ * — pack with aldm_pack_weight from a weight whose rows were permuted that way.  N (the packed
+ * width, 2*C) must be a multiple of 64, ldo >= N/2, no split-K, activation/rowbias unused.   */
+enum { ALDM_EPI_PLAIN = 0, ALDM_EPI_GEGLU = 1 };
+
 /* B-operand layouts of aldm_igemm */
 enum {
     ALDM_B_PACKED = 0, /* weights pre-packed by aldm_pack_weight: [ceil(K/4)][Npad][4]      */
@@ -101,7 +109,8 @@ typedef struct aldm_igemm_desc {
     /* ABI v2 */
     int32_t rowbias_ld;    /* row pitch of rowbias (0 => N): lets every ResBlock read its slice of
                               ONE batched timestep-embedding projection                          */
-    int32_t reserved0;
+    int32_t epi_mode;      /* ALDM_EPI_*: 0 = plain; ALDM_EPI_GEGLU fuses attention.py:42-44 (GEGLU)
+                              into the projection GEMM — see below                               */
     float* ws;             /* optional split-K workspace (caller-owned scratch, see
                               aldm_igemm_ws_floats); NULL or too small => no split-K            */
     int64_t ws_floats;     /* capacity of ws in floats                                          */

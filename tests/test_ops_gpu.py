@@ -159,6 +159,19 @@ def test_igemm_prologue_modes(ops, mode):
     assert rel_err(uncl(y), ref) < GEMM_TOL
 
 
+@pytest.mark.parametrize("M,C,inner", [(1024, 256, 1024), (300, 384, 1536), (64, 640, 2560), (70, 64, 32)])
+def test_linear_geglu_fused(ops, M, C, inner):
+    """GEGLU (attention.py:37-45) fused into the projection GEMM's epilogue vs proj -> chunk -> x*gelu(gate)."""
+    x = torch.randn(M, C, generator=g(1))
+    w = torch.randn(2 * inner, C, generator=g(2)) / math.sqrt(C)
+    b = torch.randn(2 * inner, generator=g(3))
+    val, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    y = ops.linear_geglu(x.cuda(), ops.pack_geglu(w, b))
+    assert y.shape == (M, inner)
+    assert rel_err(y, ref) < GEMM_TOL
+
+
 def test_conv_upsample_nearest(ops):
     B, C, H, W = 2, 64, 8, 4
     x = torch.randn(B, C, H, W, generator=g(1))
