@@ -3,6 +3,7 @@
 // instantiated per prologue mode in igemm_pre{0..4}.hip (parallel compilation).
 #include "igemm_kernel.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace aldm {
 

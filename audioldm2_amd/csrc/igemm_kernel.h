@@ -65,6 +65,9 @@ constexpr int igemm_min_blocks(int BM, int BN) {
     return BM * BN >= 128 * 128 ? 2 : ((BM * BN >= 64 * 128 || BN == 32) ? 3 : 4);
 }
 
+// Measured and rejected (profiles/r01_igemm_pipeline_variants_ab.txt): folding commit() into the
+// second half's MFMAs with sched_barrier fences, and a second register stage of global loads for the
+// 64x64 tile — both within +-2 % of this simpler pipeline on the UNet's shapes.
 template <int BM, int BN, int WM, int WN, int PRE>
 __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(const IgemmK p) {
     constexpr int MT = BM / (32 * WM);
@@ -160,12 +163,15 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     const int b_skg = packed ? tid / BN : akg, b_skgs = packed ? stepb : 0;
     const int b_sc = packed ? tid % BN : ar0, b_scs = packed ? 0 : 32;
 
-    f32x4 ra[PA], rb[PB];
-    f32x4 rsc[(PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) ? PA : 1];
-    f32x4 rsh[(PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) ? PA : 1];
-    unsigned avalid = 0, bvalid = 0;
+    // one in-flight k-tile of this thread's global loads
+    constexpr bool AFF = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC;
+    struct Stage {
+        f32x4 ra[PA], rb[PB];
+        f32x4 rsc[AFF ? PA : 1], rsh[AFF ? PA : 1];
+        unsigned avalid, bvalid;
+    };
 
-    auto issue_loads = [&](int kt) {
+    auto issue_loads = [&](Stage& r, int kt) {
         // ---- A: branch-free gather (invalid -> offset 0, masked at commit time) ----
         const bool kval = t_kh < d.KH;  // k < K
         const bool first = t_ci < d.C1;
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
         const int c = first ? t_ci : t_ci - d.C1;
         const int pitch = first ? pix1 : pix2;
         const int dh = t_kh * d.DH, dw = t_kw * d.DW;
-        avalid = 0;
+        r.avalid = 0;
 #pragma unroll
         for (int pp = 0; pp < PA; ++pp) {
             const int ihv = a_h[pp] + dh;
@@ -182,13 +188,13 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
             const int ih = ihv >> p.shh, iw = iwv >> p.shw;
             const int pix = ok ? (a_pix[pp] + ih) * d.W + iw : 0;
             const int64_t off = ok ? (int64_t)pix * pitch + c : 0;
-            ra[pp] = *reinterpret_cast<const f32x4*>(src + off);
-            avalid |= (ok ? 1u : 0u) << pp;
-            if constexpr (PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC) {
+            r.ra[pp] = *reinterpret_cast<const f32x4*>(src + off);
+            r.avalid |= (ok ? 1u : 0u) << pp;
+            if constexpr (AFF) {
                 if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
                     const int64_t so = ok ? (int64_t)a_b[pp] * p.Cin + t_ci : 0;
-                    rsc[pp] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
-                    rsh[pp] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
+                    r.rsc[pp] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
+                    r.rsh[pp] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
                 }
             }
         }
@@ -202,46 +208,57 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
             }
         }
         // ---- B ----
-        bvalid = 0;
+        r.bvalid = 0;
 #pragma unroll
         for (int pp = 0; pp < PB; ++pp) {
             const bool ok = kt * b_ks + pp * b_kps + b_k0 < b_klim && pp * b_nps + b_n0 < b_nlim;
             const int64_t off = ok ? kt * b_kt + pp * b_pp + b_base : 0;
-            rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
-            bvalid |= (ok ? 1u : 0u) << pp;
+            r.rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
+            r.bvalid |= (ok ? 1u : 0u) << pp;
         }
     };
 
-    auto commit = [&](int buf) {
+    // ---- commit = operand prologue on the loaded registers + LDS stores ----
+    constexpr bool ELEMWISE = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_LRELU;
+    auto xform_elem = [&](Stage& r, int pp, int c) {  // one component, in place
+        float v = r.ra[pp][c];
+        if constexpr (PRE == PRE_AFFINE) {
+            v = v * r.rsc[pp][c] + r.rsh[pp][c];
+        } else if constexpr (PRE == PRE_AFFINE_SILU) {
+            v = silu_fast(v * r.rsc[pp][c] + r.rsh[pp][c]);
+        } else if constexpr (PRE == PRE_LRELU) {
+            v = v > 0.0f ? v : v * d.pre_slope;
+        }
+        r.ra[pp][c] = v;
+    };
+    auto store_a = [&](Stage& r, int buf, int pp) {
+        f32x4 v = r.ra[pp];
+        if constexpr (PRE == PRE_GENERIC) {
+            if (d.pre_scale != nullptr) v = v * r.rsc[pp] + r.rsh[pp];
+            if (d.pre_act != ALDM_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], d.pre_act, d.pre_slope);
+            }
+        }
+        if (!((r.avalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
+        As[buf][akg][ar0 + 32 * pp] = v;
+    };
+    auto store_b = [&](Stage& r, int buf, int pp) {
+        f32x4 v = r.rb[pp];
+        if (!((r.bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        Bs[buf][b_skg + pp * b_skgs][b_sc + pp * b_scs] = v;
+    };
+    auto commit = [&](Stage& r, int buf) {
 #pragma unroll
         for (int pp = 0; pp < PA; ++pp) {
-            f32x4 v = ra[pp];
-            if constexpr (PRE == PRE_AFFINE) {
-                v = v * rsc[pp] + rsh[pp];
-            } else if constexpr (PRE == PRE_AFFINE_SILU) {
-                v = v * rsc[pp] + rsh[pp];
+            if constexpr (ELEMWISE) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = silu_fast(v[j]);
-            } else if constexpr (PRE == PRE_LRELU) {
-                const float sl = d.pre_slope;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : v[j] * sl;
-            } else if constexpr (PRE == PRE_GENERIC) {
-                if (d.pre_scale != nullptr) v = v * rsc[pp] + rsh[pp];
-                if (d.pre_act != ALDM_ACT_NONE) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], d.pre_act, d.pre_slope);
-                }
+                for (int c = 0; c < 4; ++c) xform_elem(r, pp, c);
             }
-            if (!((avalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
-            As[buf][akg][ar0 + 32 * pp] = v;
+            store_a(r, buf, pp);
         }
 #pragma unroll
-        for (int pp = 0; pp < PB; ++pp) {
-            f32x4 v = rb[pp];
-            if (!((bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            Bs[buf][b_skg + pp * b_skgs][b_sc + pp * b_scs] = v;
-        }
+        for (int pp = 0; pp < PB; ++pp) store_b(r, buf, pp);
     };
 
     f32x16 acc[MT][NT];
@@ -255,6 +272,8 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
+    // one half of a k-tile = 2 sub-steps of 8 k: one ds_read_b128 per fragment, 4 MFMAs per fragment
+    // pair and tile
     auto mma_half = [&](int buf, int half) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -274,17 +293,17 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
                                                                           acc[i][j], 0, 0, 0);
         }
     };
-
     if (kt0 < kt1) {
-        issue_loads(kt0);
-        commit(0);
+        Stage r0;
+        issue_loads(r0, kt0);
+        commit(r0, 0);
         __syncthreads();
         int buf = 0;
         for (int kt = kt0; kt + 1 < kt1; ++kt) {
-            issue_loads(kt + 1);
+            issue_loads(r0, kt + 1);
             mma_half(buf, 0);
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use (commit) behind half the MFMAs
-            commit(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use behind half the MFMAs
+            commit(r0, buf ^ 1);
             mma_half(buf, 1);
             __syncthreads();
             buf ^= 1;
@@ -304,6 +323,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     constexpr int C4 = NT * 8;        // float4 per staged row
     constexpr int RPI = 64 / C4;      // rows covered by one wave-wide float4 read
     constexpr int IT = 32 / RPI;      // reads per 32-row slab
+    constexpr int ITC = IT < 4 ? IT : 4;  // ... processed ITC at a time
     static_assert(4 * 32 * SP * 4 <= (A_F4 + B_F4) * 16, "staging must fit the K-loop LDS");
     __syncthreads();  // every wave is done reading As/Bs
     float* stg = reinterpret_cast<float*>(&smem[0]) + wave * (32 * SP);
@@ -367,14 +387,16 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][e];
-        // LDS -> float4 per lane
-        f32x4 v[IT];
-        int64_t rowoff[IT];
-        int rboff[IT];
+        // LDS -> float4 per lane, ITC wave-wide reads at a time (bounds the live registers)
+#pragma unroll
+        for (int itc = 0; itc < IT; itc += ITC) {
+        f32x4 v[ITC];
+        int64_t rowoff[ITC];
+        int rboff[ITC];
         unsigned okmask = 0;
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int r = it * RPI + sr;
+        for (int it = 0; it < ITC; ++it) {
+            const int r = (itc + it) * RPI + sr;
             v[it] = *reinterpret_cast<const f32x4*>(&stg[r * SP + sc]);
             const int m = m0 + (wm * MT + i) * 32 + r;
             bool ok = m < p.M && ncol < d.N;
@@ -395,15 +417,15 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
         }
         if (split_out) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
+            for (int it = 0; it < ITC; ++it)
                 if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
             continue;
         }
 #pragma unroll
-        for (int it = 0; it < IT; ++it) v[it] += bias4;
+        for (int it = 0; it < ITC; ++it) v[it] += bias4;
         if (d.rowbias) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
+            for (int it = 0; it < ITC; ++it)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[it][c] += d.rowbias[rboff[it] + (ncol + c < d.N ? c : 0)];
         }
@@ -411,19 +433,19 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
             case ALDM_ACT_NONE: break;
             case ALDM_ACT_SILU:
 #pragma unroll
-                for (int it = 0; it < IT; ++it)
+                for (int it = 0; it < ITC; ++it)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], ALDM_ACT_SILU, 0.f);
                 break;
             case ALDM_ACT_GELU:
 #pragma unroll
-                for (int it = 0; it < IT; ++it)
+                for (int it = 0; it < ITC; ++it)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], ALDM_ACT_GELU, 0.f);
                 break;
             default:
 #pragma unroll
-                for (int it = 0; it < IT; ++it)
+                for (int it = 0; it < ITC; ++it)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], d.act, d.act_slope);
                 break;
@@ -431,20 +453,20 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
         if (vec) {
             if (resp) {
 #pragma unroll
-                for (int it = 0; it < IT; ++it) v[it] += *reinterpret_cast<const f32x4*>(resp + rowoff[it]);
+                for (int it = 0; it < ITC; ++it) v[it] += *reinterpret_cast<const f32x4*>(resp + rowoff[it]);
             }
 #pragma unroll
-            for (int it = 0; it < IT; ++it) v[it] *= d.alpha;
+            for (int it = 0; it < ITC; ++it) v[it] *= d.alpha;
             if (d.accumulate) {
 #pragma unroll
-                for (int it = 0; it < IT; ++it) v[it] += *reinterpret_cast<const f32x4*>(outp + rowoff[it]);
+                for (int it = 0; it < ITC; ++it) v[it] += *reinterpret_cast<const f32x4*>(outp + rowoff[it]);
             }
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
+            for (int it = 0; it < ITC; ++it)
                 if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
         } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
+            for (int it = 0; it < ITC; ++it)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (!((okmask >> it) & 1u) || ncol + c >= d.N) continue;
@@ -455,6 +477,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
                     outp[rowoff[it] + c] = x;
                 }
         }
+        }  // itc
     }
 }
 
