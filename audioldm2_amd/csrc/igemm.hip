@@ -13,6 +13,7 @@ int igemm_launch_pre1(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p
 int igemm_launch_pre2(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_pre3(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_pre4(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre5(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -168,6 +169,13 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.pre_scale == nullptr ||
                    ((reinterpret_cast<uintptr_t>(d.pre_scale) | reinterpret_cast<uintptr_t>(d.pre_shift)) & 15) == 0,
                "aldm_igemm: pre_scale/pre_shift must be 16-byte aligned");
+    if (d.pre_rowstats != nullptr) {
+        ALDM_CHECK(d.pre_scale && d.pre_shift && d.pre_act == ALDM_ACT_NONE && d.C2 == 0 && d.KH == 1 && d.KW == 1 &&
+                       d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.up_h == 1 && d.up_w == 1 &&
+                       d.OH == d.H && d.OW == d.W,
+                   "aldm_igemm: the row-norm prologue needs a plain row-major GEMM (1x1, no stride/pad/upsample/"
+                   "concat) with gamma/beta in pre_scale/pre_shift");
+    }
     const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
     ALDM_CHECK(d.epi_mode == ALDM_EPI_PLAIN || geglu, "aldm_igemm: unknown epi_mode %d", d.epi_mode);
     if (geglu) {
@@ -302,7 +310,8 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits, (unsigned)d.batch);
     hipStream_t st = (hipStream_t)stream;
     int pre;
-    if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_NONE;
+    if (d.pre_rowstats != nullptr) pre = PRE_ROWNORM;
+    else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_NONE;
     else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_AFFINE;
     else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_SILU) pre = PRE_AFFINE_SILU;
     else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) pre = PRE_LRELU;
@@ -312,6 +321,7 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
         case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, grid, st, p); break;
         case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, grid, st, p); break;
         case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, grid, st, p); break;
+        case PRE_ROWNORM: rc = igemm_launch_pre5(BM, BN, grid, st, p); break;
         default: rc = igemm_launch_pre4(BM, BN, grid, st, p); break;
     }
     if (rc) {

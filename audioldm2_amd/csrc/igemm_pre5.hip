@@ -1,0 +1,18 @@
+// igemm_pre5.hip — instantiations of the implicit-GEMM kernel for prologue mode 5 (see igemm_kernel.h).
+#include "igemm_kernel.h"
+
+namespace aldm {
+int igemm_launch_pre5(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p) {
+    constexpr int PRE = 5;
+#define ALDM_IG(BM_, BN_, WM_, WN_) \
+    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE>), grid, dim3(256), 0, st, p)
+    if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2);
+    else if (BM == 128 && BN == 64) ALDM_IG(128, 64, 2, 2);
+    else if (BM == 128 && BN == 32) ALDM_IG(128, 32, 4, 1);
+    else if (BM == 64 && BN == 128) ALDM_IG(64, 128, 2, 2);
+    else if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2);
+    else return -1;
+#undef ALDM_IG
+    return 0;
+}
+}  // namespace aldm

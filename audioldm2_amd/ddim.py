@@ -44,14 +44,36 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     return torch.as_tensor(np.asarray(sigmas, dtype=np.float64)), alphas, alphas_prev
 
 
+class GraphStepper:
+    """Runs a fixed launch sequence repeatedly: eagerly the first time (packs weights, warms the
+    allocator, grows the split-K workspace), captured into a HIP graph the second time, replayed after.
+    The callable must read its per-step inputs from static device buffers."""
+
+    def __init__(self, fn, use_graph=True):
+        self.fn, self.use_graph, self.calls, self.graph = fn, use_graph, 0, None
+
+    def __call__(self):
+        if self.use_graph and self.calls >= 1:
+            if self.graph is None:
+                self.graph = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(self.graph):
+                    self.fn()
+            self.graph.replay()
+        else:
+            self.fn()
+        self.calls += 1
+
+
 class _NoiseFeed:
     """Streams the per-step host noise to the GPU in chunks, overlapping the CPU generator (the
     reference's RNG stream, drawn strictly in its order) and the PCIe upload with the UNet steps of the
     previous chunk: chunk c+1 is drawn and uploaded on a side stream while the GPU runs chunk c.
     Device buffers hold all steps; `wait(i)` makes the current stream wait for step i's chunk."""
 
-    def __init__(self, draw, steps, shape, with_mask, temperature, dev, chunk=8):
+    def __init__(self, draw, steps, shape, with_mask, temperature, dev, chunk=8, mask_first=True):
         self.draw, self.steps, self.with_mask, self.temperature = draw, steps, with_mask, temperature
+        self.mask_first = mask_first  # DDIM draws the q_sample noise before the step noise, DDPM after
         self.chunk = chunk
         self.noise = torch.empty((steps,) + tuple(shape), device=dev, dtype=torch.float32)
         self.qnoise = torch.empty_like(self.noise) if with_mask else None
@@ -72,11 +94,13 @@ class _NoiseFeed:
         prev = self.events.get(c - len(self.pin))
         if prev is not None:
             prev.synchronize()  # the upload that last used this pinned slot is done
-        for s in range(lo, hi):  # reference order per step: [q_sample noise], step noise
-            if self.with_mask:
+        for s in range(lo, hi):  # reference order per step
+            if self.with_mask and self.mask_first:
                 self.qpin[slot][s - lo].copy_(self.draw())
             n = self.draw()
             self.pin[slot][s - lo].copy_(n * self.temperature if self.temperature != 1.0 else n)
+            if self.with_mask and not self.mask_first:
+                self.qpin[slot][s - lo].copy_(self.draw())
         with torch.cuda.stream(self.stream):
             self.noise[lo:hi].copy_(self.pin[slot][:hi - lo], non_blocking=True)
             if self.with_mask:
@@ -212,8 +236,9 @@ class DDIMSampler(object):
             assert x0 is not None
             mask_d = mask.float().to(dev).expand(shape).contiguous()
             x0_d = x0.float().to(dev).contiguous()
-            sa = self.sqrt_alphas_cumprod[torch.from_numpy(np.ascontiguousarray(time_range - 0))].to(dev)
-            so = self.sqrt_one_minus_alphas_cumprod[torch.from_numpy(np.ascontiguousarray(time_range - 0))].to(dev)
+            tr = torch.from_numpy(np.ascontiguousarray(time_range - 0))
+            blend_coef = torch.stack([self.sqrt_alphas_cumprod[tr], self.sqrt_one_minus_alphas_cumprod[tr]],
+                                     1).contiguous().to(dev)  # [S, 2] = {sqrt(abar_t), sqrt(1 - abar_t)}
 
         # static buffers = the graph's inputs
         x_cur = img.clone()
@@ -242,7 +267,7 @@ class DDIMSampler(object):
             ops.ddim_step(x_cur, eps, noise_cur, coef_cur, x_next, pred_x0)
             x_cur.copy_(x_next)
 
-        graph = None
+        run_step = GraphStepper(step, self.use_graph)
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         for i, step_t in enumerate(time_range):
             index = total_steps - i - 1
@@ -252,17 +277,8 @@ class DDIMSampler(object):
             noise_cur.copy_(noise[i])
             if mask is not None:
                 # img = q_sample(x0, ts)*mask + (1-mask)*img   (ddim.py:226-231, ddpm.py:430-436)
-                img_orig = sa[i] * x0_d + so[i] * qn[i]
-                x_cur.copy_(img_orig * mask_d + (1.0 - mask_d) * x_cur)
-            if self.use_graph and i >= 1:
-                if graph is None:
-                    graph = torch.cuda.CUDAGraph()
-                    torch.cuda.synchronize()
-                    with torch.cuda.graph(graph):
-                        step()
-                graph.replay()
-            else:
-                step()  # first step runs eagerly: packs weights, warms the allocator
+                ops.inpaint_blend(x_cur, x0_d, qn[i], mask_d, blend_coef[i])
+            run_step()  # eager the first time, then one HIP-graph replay per step
             if i % feed.chunk == 0:
                 feed.produce_next()  # draw + upload the NEXT chunk while the GPU works on this one
             if callback:

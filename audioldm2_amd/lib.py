@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaldm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
 B_PACKED, B_NT = 0, 1
@@ -43,6 +43,7 @@ class IgemmDesc(C.Structure):
         ("stride_x", C.c_int64), ("stride_w", C.c_int64), ("stride_o", C.c_int64),
         ("rowbias_ld", C.c_int32), ("epi_mode", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("pre_rowstats", C.c_void_p),
     ]
 
 
@@ -62,6 +63,7 @@ _SIGS = {
                                        C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "aldm_gn_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aldm_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_void_p]),
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -77,6 +79,10 @@ _SIGS = {
     "aldm_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_ddim_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_void_p]),
+    "aldm_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p]),
+    "aldm_inpaint_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p]),
     "aldm_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64,
                              C.c_void_p]),
     "aldm_reflect_pad_1d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

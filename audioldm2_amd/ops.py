@@ -133,7 +133,7 @@ def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
     return pack_conv(weight.detach()[perm], None if bias is None else bias.detach()[perm])
 
 
-def linear_geglu(x: torch.Tensor, pw: Packed) -> torch.Tensor:
+def linear_geglu(x: torch.Tensor, pw: Packed, rownorm=None) -> torch.Tensor:
     """y = value * gelu_erf(gate) with [value | gate] = x @ W^T + b fused into the GEMM epilogue
     (attention.py:37-45); pw from pack_geglu.  x: [..., Cin] -> [..., N/2]."""
     _chk(x, "linear_geglu.x")
@@ -148,6 +148,10 @@ def linear_geglu(x: torch.Tensor, pw: Packed) -> torch.Tensor:
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
     d.bias = _p(pw.bias); d.out = out.data_ptr(); d.ldo = pw.N // 2; d.alpha = 1.0
     d.epi_mode = _l.EPI_GEGLU; d.batch = 1
+    if rownorm is not None:
+        st, ga, be = rownorm
+        assert st.shape == (M, 2) and ga.numel() == pw.Cin and be.numel() == pw.Cin
+        d.pre_rowstats = st.data_ptr(); d.pre_scale = ga.data_ptr(); d.pre_shift = be.data_ptr()
     _igemm(d, "igemm(geglu)")
     return out
 
@@ -176,7 +180,8 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
          act: int = ACT_NONE, act_slope: float = 0.0, alpha: float = 1.0,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
          remap: Optional[Tuple[int, int, int]] = None,
-         use_pw_bias: bool = True) -> torch.Tensor:
+         use_pw_bias: bool = True,
+         rownorm: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """Implicit-GEMM convolution (aldm_igemm).  x: [B, H, W, C1] (+ x2: [B, H, W, C2] concatenated
     along C).  Returns [B, OH, OW, N] (or the remapped [B, 1, out_len, N])."""
     _chk(x, "conv.x")
@@ -217,6 +222,11 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.OH = OH; d.OW = OW
     if pre is not None:
         d.pre_scale = pre[0].data_ptr(); d.pre_shift = pre[1].data_ptr()
+    if rownorm is not None:  # fused LayerNorm: (stats [M, 2], gamma [C], beta [C])
+        assert pre is None and pre_act == ACT_NONE and x2 is None
+        st, ga, be = rownorm
+        assert st.shape == (B * OH * OW, 2) and ga.numel() == C1 and be.numel() == C1
+        d.pre_rowstats = st.data_ptr(); d.pre_scale = ga.data_ptr(); d.pre_shift = be.data_ptr()
     d.pre_act = pre_act; d.pre_slope = pre_slope
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
     d.K = pw.K; d.N = N
@@ -324,6 +334,17 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups
     return ss[0], ss[1]
 
 
+def row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm statistics of [..., C] rows -> [M, 2] = {mean, rstd}; the normalisation itself is fused
+    into the consuming GEMM (conv/linear/linear_geglu `rownorm=(stats, gamma, beta)`)."""
+    _chk(x, "row_stats.x")
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    st = torch.empty((M, 2), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_row_stats(x.data_ptr(), st.data_ptr(), M, Cc, eps, _stream()), "row_stats")
+    return st
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
     _chk(x, "ln.x")
     Cc = x.shape[-1]
@@ -417,6 +438,30 @@ def ddim_step(x: torch.Tensor, eps: torch.Tensor, noise: torch.Tensor, coef: tor
                                       x_prev.data_ptr(), pred_x0.data_ptr(), x.numel(), _stream()),
              "ddim_step")
     return x_prev, pred_x0
+
+
+def ddpm_step(x: torch.Tensor, eps: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor,
+              x_prev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Ancestral DDPM update (ddpm.py:357-373, 1127-1181); coef: device [>=5] row, see aldm_hip.h."""
+    for t, n in ((x, "x"), (eps, "eps"), (noise, "noise"), (coef, "coef")):
+        _chk(t, "ddpm." + n)
+    if x_prev is None:
+        x_prev = torch.empty_like(x)
+    _l.check(_l.load().aldm_ddpm_step(x.data_ptr(), eps.data_ptr(), noise.data_ptr(), coef.data_ptr(),
+                                      x_prev.data_ptr(), x.numel(), _stream()), "ddpm_step")
+    return x_prev
+
+
+def inpaint_blend(x: torch.Tensor, x0: torch.Tensor, qnoise: torch.Tensor, mask: torch.Tensor,
+                  coef: torch.Tensor) -> torch.Tensor:
+    """In place: x = q_sample(x0, t; qnoise)*mask + (1-mask)*x (ddim.py:226-231); coef = {sa, so}."""
+    for t, n in ((x, "x"), (x0, "x0"), (qnoise, "qnoise"), (mask, "mask"), (coef, "coef")):
+        _chk(t, "inpaint." + n)
+    assert x.shape == x0.shape == qnoise.shape == mask.shape
+    _l.check(_l.load().aldm_inpaint_blend(x0.data_ptr(), qnoise.data_ptr(), mask.data_ptr(),
+                                          coef.data_ptr(), x.data_ptr(), x.numel(), _stream()),
+             "inpaint_blend")
+    return x
 
 
 def axpby(a: torch.Tensor, b: Optional[torch.Tensor], alpha: float, beta: float = 0.0,

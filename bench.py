@@ -27,9 +27,11 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-AUDIO_SECONDS = 163872 / 16000.0  # delivered samples per prompt (10.242 s)
-UNET_GFLOP_PER_FWD_SAMPLE = 171.20  # SURVEY.md §8(d), audioldm2-full, L_T5 = 32
+# algorithmic GFLOP of ONE UNet forward of ONE sample (2*MAC of conv/mm/bmm/addmm)
+UNET_GFLOP_PER_FWD_SAMPLE = {"audioldm2-full": 171.20, "audioldm2-full-large-1150k": 353.69,
+                             "audioldm2-speech-gigaspeech": 151.85, "audioldm_48k": 145.40}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -42,6 +44,7 @@ def parse():
     ap.add_argument("--model", default="audioldm2-full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-step-probe", action="store_true")
     ap.add_argument("--cpu-ddim-steps", type=int, default=8)
     return ap.parse_args()
 
@@ -75,9 +78,22 @@ def roofline_probe(ld, batch, B):
     achieved = fl / sec / 1e12
     tot_fl = sum(v[1] for v in agg.values())
     tot_s = sum(v[2] for v in agg.values())
+    # HBM traffic of the same kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, separate runs) of this
+    # command, committed under profiles/ (tools/pmc_traffic.py); null when that file is absent
+    traffic, traffic_src = None, None
+    if os.path.exists(TRAFFIC_JSON):
+        with open(TRAFFIC_JSON) as f:
+            tj = json.load(f)
+        ent = tj.get("kernels", {}).get(f"igemm_kernel<{bm}, {bn}>")
+        if ent:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_src = {"file": "profiles/r01_pmc_traffic.json", "launches": ent["launches"],
+                           "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
+                           "write_bytes_per_launch": ent["write_bytes_per_launch"],
+                           "algorithmic_min_bytes_per_launch": ent.get("note")}
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": f"aldm::igemm_kernel<{bm},{bn}>", "launches_per_unet_pass": n,
         "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
         "all_igemm_tflops": round(tot_fl / tot_s / 1e12, 2),
@@ -132,7 +148,7 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
     t_voc = time.time() - t0
     step_s = t_loop / ddim_steps_sample
     total = step_s * total_steps + t_dec + t_voc
-    return {"value": round(AUDIO_SECONDS / total, 5), "unit": "audio-s/s", "cores": threads, "kind": "port",
+    return {"value": round((163872 / 16000.0) / total, 5), "unit": "audio-s/s", "cores": threads, "kind": "port",
             "sample": (f"CPU oracle (torch fp32, {threads} threads), B=1: {ddim_steps_sample} DDIM steps timed "
                        f"({step_s*1e3:.0f} ms/step) x{total_steps} extrapolated + VAE decode {t_dec:.2f}s + "
                        f"vocoder {t_voc:.2f}s"),
@@ -182,26 +198,31 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert wav.shape == (B, 1, 163872) and np.isfinite(wav).all()
+    assert wav.shape[:2] == (B, 1) and np.isfinite(wav).all()
+    audio_seconds = wav.shape[-1] / float(ld.sampling_rate)  # delivered audio per prompt (10.24 s)
+    khz = ld.sampling_rate // 1000
 
     if rank == 0:
-        value = gB * AUDIO_SECONDS * args.steps / dt
+        value = gB * audio_seconds * args.steps / dt
         out = {
             "metric": "audio_seconds_per_second", "value": round(value, 3), "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model}: batch {B} prompts/GPU x {world} GPU, 10.24 s @16 kHz, "
+            "config": {"workload": f"{args.model}: batch {B} prompts/GPU x {world} GPU, {audio_seconds:.2f} s @{khz} kHz, "
                                    f"{args.ddim_steps} DDIM steps, CFG 3.5, eta 1.0, n_candidates 1; one step = "
                                    "sample_log + VAE decode + HiFi-GAN + D2H of the waveform; synthetic "
-                                   "conditioning (T5 length 32), random-init weights, host-CPU RNG noise",
+                                   "conditioning, random-init weights, host-CPU RNG noise",
                        "global_batch": gB, "parallelism": f"prompt-sharded replicas x{world}",
                        "weight_broadcast_bytes": bcast_bytes},
         }
         try:
+            if args.no_step_probe:
+                raise RuntimeError("skipped (--no-step-probe)")
             step_ms = unet_step_probe(ld, make_batch_for_text_to_audio("synthetic prompt", batchsize=B), B)
             out["unet_step_ms"] = round(step_ms, 3)
-            out["unet_step_tflops"] = round(2 * UNET_GFLOP_PER_FWD_SAMPLE * B / step_ms, 2)  # GFLOP/ms = TFLOP/s
+            gf = UNET_GFLOP_PER_FWD_SAMPLE[args.model]
+            out["unet_step_tflops"] = round(2 * gf * B / step_ms, 2)  # GFLOP/ms = TFLOP/s
             out["unet_step_frac_of_f32_mfma_peak"] = round(out["unet_step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
         except Exception as e:  # pragma: no cover
             out["unet_step_ms"] = f"probe failed: {e}"

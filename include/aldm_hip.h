@@ -114,6 +114,11 @@ typedef struct aldm_igemm_desc {
     float* ws;             /* optional split-K workspace (caller-owned scratch, see
                               aldm_igemm_ws_floats); NULL or too small => no split-K            */
     int64_t ws_floats;     /* capacity of ws in floats                                          */
+    /* ABI v3: LayerNorm fused into the consuming GEMM (attention.py:393-395 -> :335-342 / :40).
+       pre_rowstats: [M][2] = {mean, rstd} per GEMM row from aldm_row_stats; pre_scale / pre_shift
+       then hold gamma / beta [K] and a = (a - mean[m]) * rstd[m] * gamma[k] + beta[k].  Plain
+       row-major GEMMs only (1x1, no stride/pad/upsample/concat).                               */
+    const float* pre_rowstats;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -151,6 +156,9 @@ int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1,
                          int G, float eps, const float* gamma, const float* beta,
                          float* scale, float* shift, float* ws, void* stream);
 int64_t aldm_gn_ws_floats(int B, int P, int C, int G);
+/* Per-row LayerNorm statistics of [M, C]: stats[m] = {mean, 1/sqrt(var + eps)} (exact two-pass,
+ * biased variance), consumed by aldm_igemm's pre_rowstats prologue.                            */
+int aldm_row_stats(const float* x, float* stats, int M, int C, float eps, void* stream);
 /* LayerNorm over the last dim of [M, C] (attention.py:393-395), eps 1e-5                   */
 int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                    const float* beta, float eps, void* stream);
@@ -184,6 +192,16 @@ int aldm_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stre
  *   e = e_u + s*(e_c - e_u); pred_x0 = (x - c0*e)/c1; x_prev = c3*pred_x0 + c2*e + c4*noise  */
 int aldm_ddim_step(const float* x, const float* eps, const float* noise, const float* coef,
                    float* x_prev, float* pred_x0, int64_t n, void* stream);
+/* Ancestral DDPM step (LatentDiffusion.sample -> p_sample, ddpm.py:357-373,1127-1181), reference
+ * operation order: x_recon = a*x - b*eps; mean = c1*x_recon + c2*x; x_prev = mean + s*noise with
+ * coef (device) = {sqrt(1/abar_t), sqrt(1/abar_t - 1), posterior_mean_coef1, posterior_mean_coef2,
+ * nonzero_mask*exp(0.5*posterior_log_variance_clipped)}.                                        */
+int aldm_ddpm_step(const float* x, const float* eps, const float* noise, const float* coef,
+                   float* x_prev, int64_t n, void* stream);
+/* Inpainting blend, in place on x (ddim.py:226-231, q_sample ddpm.py:430-436):
+ *   x = (sa*x0 + so*qnoise)*mask + (1 - mask)*x,  coef (device) = {sqrt(abar_t), sqrt(1 - abar_t)} */
+int aldm_inpaint_blend(const float* x0, const float* qnoise, const float* mask, const float* coef,
+                       float* x, int64_t n, void* stream);
 /* generic y = alpha*a + beta*b (b may be NULL) */
 int aldm_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n,
                void* stream);

@@ -103,3 +103,13 @@ def e2e_batch(B: int):
     return {"text": text, "fname": [t.replace(" ", "_") for t in text], "waveform": torch.zeros((B, 160000)),
             "stft": torch.zeros((B, 1024, 512)), "log_mel_spec": fbank, "fbank": fbank,
             "ta_kaldi_fbank": torch.zeros((B, 1024, 128)), "phoneme_idx": torch.zeros((B, 310), dtype=torch.long)}
+
+
+def e2e_masked_batch(B: int):
+    """Inpainting / super-resolution input: the e2e batch with a real (seeded, log-mel-range) fbank
+    [B, 1024, 64] in place of the all-zero one (pipeline.py:238-242)."""
+    b = e2e_batch(B)
+    fb = mel_input(B, 64, 1024, seed=11).permute(0, 2, 1).contiguous()
+    b["log_mel_spec"] = fb
+    b["fbank"] = fb
+    return b

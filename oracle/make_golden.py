@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference with the
 import stubs of oracle/refimport.py) on the seeded cases of oracle/cases.py.  TEST INFRA ONLY; run
-in the build container:  python -m oracle.make_golden [all|unet|vae|hifigan|ddim|stft|e2e5|e2e200]
+in the build container:  python -m oracle.make_golden [all|unet|vae|hifigan|ddim|stft|e2e5|masked|ancestral|e2e200]
 
 The reference ships no golden vectors; these fixtures are what pins both the oracle
 restatement (tests/test_oracle.py, CPU) and the HIP product (tests/test_*_gpu.py) to the reference.
@@ -194,6 +194,60 @@ def gen_e2e(steps: int, B: int, name: str):
     save(name, latent=rec["latent"], mel=rec["mel"], wave=wav, seconds=np.float32(dt), threads=np.int32(torch.get_num_threads()))
 
 
+def _seed_all():
+    import random
+    random.seed(cases.E2E_SEED)
+    np.random.seed(cases.E2E_SEED)
+    torch.manual_seed(cases.E2E_SEED)
+
+
+def gen_e2e_masked(steps: int, B: int, name: str):
+    """Reference LatentDiffusion.generate_batch_masked (ddpm.py:1573-1676): VAE-encode a real mel,
+    time/frequency mask, DDIM with the q_sample blend (ddim.py:226-231), decode, vocode."""
+    ld = _ref_latent_diffusion()
+    ld.latent_t_size = 256
+    rec = {}
+    orig_decode, orig_sample_log = ld.decode_first_stage, ld.sample_log
+
+    def decode_hook(z):
+        rec["latent"] = z.clone()
+        mel = orig_decode(z)
+        rec["mel"] = mel.clone()
+        return mel
+
+    def sample_log_hook(*a, **k):
+        rec["x0"] = k["x0"].clone()
+        rec["mask"] = k["mask"].clone()
+        return orig_sample_log(*a, **k)
+    ld.decode_first_stage, ld.sample_log = decode_hook, sample_log_hook
+    _seed_all()
+    t0 = time.time()
+    wav = ld.generate_batch_masked(cases.e2e_masked_batch(B), unconditional_guidance_scale=2.5, ddim_steps=steps,
+                                   n_gen=1, duration=10, time_mask_ratio_start_and_end=(0.25, 0.75),
+                                   freq_mask_ratio_start_and_end=(0.75, 1.0))
+    dt = time.time() - t0
+    print(f"{name}: reference generate_batch_masked B={B} steps={steps}: {dt:.1f}s wave rms {np.sqrt((wav**2).mean()):.4f}"
+          f" latent std {rec['latent'].std():.3f} x0 std {rec['x0'].std():.3f}")
+    save(name, x0=rec["x0"], mask=rec["mask"], latent=rec["latent"], mel=rec["mel"], wave=wav)
+
+
+def gen_ancestral(T: int, B: int, name: str):
+    """Reference LatentDiffusion.sample -> p_sample_loop (ddpm.py:1350-1391, 1276-1347) for the last T
+    timesteps (timesteps=T), no CFG (the ancestral path has none)."""
+    ld = _ref_latent_diffusion()
+    ld.latent_t_size = 256
+    batch = cases.e2e_batch(B)
+    cond = {}
+    for key, meta in ld.cond_stage_model_metadata.items():
+        m = ld.cond_stage_models[meta["model_idx"]]
+        cond[key] = m(batch if meta["cond_stage_key"] == "all" else batch[meta["cond_stage_key"]])
+    _seed_all()
+    t0 = time.time()
+    z, inter = ld.sample(cond, batch_size=B, return_intermediates=True, timesteps=T, verbose=False, log_every_t=1)
+    print(f"{name}: reference sample(timesteps={T}) B={B}: {time.time()-t0:.1f}s latent std {z.std():.3f}")
+    save(name, latent=z, first=inter[1])
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
     torch.set_grad_enabled(False)
@@ -209,5 +263,9 @@ if __name__ == "__main__":
         gen_stft()
     if "all" in what or "e2e5" in what:
         gen_e2e(5, 2, "e2e_full_5step_b2")
+    if "all" in what or "masked" in what:
+        gen_e2e_masked(4, 1, "e2e_masked_4step_b1")
+    if "all" in what or "ancestral" in what:
+        gen_ancestral(4, 1, "ancestral_4step_b1")
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")

@@ -17,9 +17,9 @@ from typing import Dict, Optional
 import torch
 
 from . import cases, weights
-from .ddim import ddim_sample, make_schedule_buffers
+from .ddim import ancestral_sample, ddim_sample, make_schedule_buffers
 from .unet import unet_forward
-from .vae import hifigan_forward, vae_decode
+from .vae import hifigan_forward, vae_decode, vae_encode_moments
 
 _GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -70,3 +70,39 @@ class OracleLatentDiffusion:
         wave = hifigan_forward(self.sd, self.hcfg, mel.squeeze(1).permute(0, 2, 1),
                                prefix="first_stage_model.vocoder.")
         return {"latent": z, "mel": mel, "wave": wave.numpy()}
+
+    @torch.no_grad()
+    def generate_batch_masked(self, batch, unconditional_guidance_scale=2.5, ddim_steps=200, ddim_eta=1.0,
+                              time_mask_ratio_start_and_end=(0.25, 0.75), freq_mask_ratio_start_and_end=(0.75, 1.0)):
+        """ddpm.py:1573-1676 for n_gen = 1: encode the mel (posterior sample on the host generator,
+        distributions.py:37-41; x scale_factor, ddpm.py:793-802), mask, masked DDIM, decode, vocode."""
+        x = batch["log_mel_spec"].unsqueeze(1).float()
+        moments = vae_encode_moments(self.sd, self.dd, x, prefix="first_stage_model.")
+        mean, logvar = torch.chunk(moments, 2, dim=1)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        z = torch.tensor(self.scale_factor) * (mean + std * torch.randn(mean.shape))
+        B, _, h, w = z.shape
+        cond = {k: m(batch if self.cond_stage_key[k] == "all" else batch[self.cond_stage_key[k]])
+                for k, m in self.cond_models.items()}
+        mask = torch.ones(B, h, w)
+        mask[:, int(h * time_mask_ratio_start_and_end[0]):int(h * time_mask_ratio_start_and_end[1]), :] = 0
+        mask[:, :, int(w * freq_mask_ratio_start_and_end[0]):int(w * freq_mask_ratio_start_and_end[1])] = 0
+        mask = mask[:, None]
+        uncond = None
+        if unconditional_guidance_scale != 1.0:
+            uncond = {k: m.get_unconditional_condition(B) for k, m in self.cond_models.items()}
+        lat = ddim_sample(self.apply_model, (B, self.channels, h, w), cond, uncond, unconditional_guidance_scale,
+                          ddim_steps, ddim_eta, self.buffers["alphas_cumprod"], mask=mask, x0=z)
+        mel = vae_decode(self.sd, self.dd, (1.0 / torch.tensor(self.scale_factor)) * lat, prefix="first_stage_model.")
+        wave = hifigan_forward(self.sd, self.hcfg, mel.squeeze(1).permute(0, 2, 1),
+                               prefix="first_stage_model.vocoder.")
+        return {"x0": z, "mask": mask, "latent": lat, "mel": mel, "wave": wave.numpy()}
+
+    @torch.no_grad()
+    def sample_ancestral(self, batch, timesteps: int):
+        """LatentDiffusion.sample (ddpm.py:1350-1391) for the last `timesteps` steps, no CFG."""
+        B = len(batch["text"])
+        cond = {k: m(batch if self.cond_stage_key[k] == "all" else batch[self.cond_stage_key[k]])
+                for k, m in self.cond_models.items()}
+        shape = (B, self.channels, self.latent_t_size, self.latent_f_size)
+        return ancestral_sample(self.apply_model, shape, cond, timesteps)

@@ -172,6 +172,24 @@ def test_linear_geglu_fused(ops, M, C, inner):
     assert rel_err(y, ref) < GEMM_TOL
 
 
+@pytest.mark.parametrize("M,C,N", [(1024, 256, 768), (300, 384, 384), (70, 640, 1920)])
+def test_linear_with_fused_layernorm(ops, M, C, N):
+    """LayerNorm (attention.py:393-395) fused into the consuming Linear's operand gather (row statistics
+    kernel + PRE_ROWNORM) vs F.layer_norm -> F.linear, and bitwise vs the unfused HIP LayerNorm + linear."""
+    x = torch.randn(M, C, generator=g(1)) * 3 + 0.7
+    w = torch.randn(N, C, generator=g(2)) / math.sqrt(C)
+    b = torch.randn(N, generator=g(3))
+    ga, be = torch.randn(C, generator=g(4)), torch.randn(C, generator=g(5))
+    ref = F.linear(F.layer_norm(x, (C,), ga, be, 1e-5), w, b)
+    pw = ops.pack_conv(w, b)
+    xs = x.cuda()
+    st = ops.row_stats(xs)
+    y = ops.linear(xs, pw, rownorm=(st, ga.cuda(), be.cuda()))
+    assert rel_err(y, ref) < GEMM_TOL
+    y2 = ops.linear(ops.layernorm(xs, ga.cuda(), be.cuda()), pw)
+    assert torch.equal(y, y2), "fused and unfused LayerNorm must agree bit for bit (same operation order)"
+
+
 def test_conv_upsample_nearest(ops):
     B, C, H, W = 2, 64, 8, 4
     x = torch.randn(B, C, H, W, generator=g(1))
@@ -402,6 +420,25 @@ def test_layout_and_ddim_step(ops):
                          s, 1.0, 0.0]).cuda()
     gx, gp = ops.ddim_step(x.cuda(), torch.stack([eu, ec]).cuda(), nz.cuda(), coef)
     assert rel_err(gx, xp) < EW_TOL and rel_err(gp, pred) < EW_TOL
+
+
+def test_ddpm_step_and_inpaint_blend(ops):
+    """Ancestral update (ddpm.py:357-373, 1127-1181) and the inpainting blend (ddim.py:226-231)."""
+    x = torch.randn(2, 8, 12, 16, generator=g(1))
+    e = torch.randn(2, 8, 12, 16, generator=g(2))
+    nz = torch.randn(2, 8, 12, 16, generator=g(3))
+    a, b, c1, c2, sg = 1.31, 0.85, 0.07, 0.93, 0.11
+    x0 = a * x - b * e
+    ref = (c1 * x0 + c2 * x) + sg * nz
+    got = ops.ddpm_step(x.cuda(), e.cuda(), nz.cuda(), torch.tensor([a, b, c1, c2, sg, 0, 0, 0]).cuda())
+    assert rel_err(got, ref) < EW_TOL
+    mask = (torch.rand(2, 8, 12, 16, generator=g(4)) > 0.5).float()
+    xs = torch.randn(2, 8, 12, 16, generator=g(5))
+    sa, so = 0.6, 0.8
+    ref2 = (sa * xs + so * nz) * mask + (1.0 - mask) * x
+    xc = x.clone().cuda()
+    ops.inpaint_blend(xc, xs.cuda(), nz.cuda(), mask.cuda(), torch.tensor([sa, so]).cuda())
+    assert rel_err(xc, ref2) < EW_TOL
 
 
 def test_error_reporting(ops):

@@ -124,3 +124,28 @@ def test_e2e_oracle_matches_reference_generate_batch_5step():
     assert rel(out["latent"], g["latent"]) < 1e-4
     assert rel(out["mel"], g["mel"]) < 1e-4
     assert rel(out["wave"], g["wave"]) < 1e-4
+
+
+def test_e2e_oracle_matches_reference_generate_batch_masked():
+    """Inpainting / super-resolution path vs the real LatentDiffusion.generate_batch_masked fixture
+    (B=1, 4 DDIM steps, CFG 2.5, seed 42): VAE encode + posterior draw, mask, q_sample blend order."""
+    from oracle.pipeline import OracleLatentDiffusion
+    g = gold("e2e_masked_4step_b1")
+    o = OracleLatentDiffusion()
+    torch.manual_seed(cases.E2E_SEED)
+    out = o.generate_batch_masked(cases.e2e_masked_batch(1), unconditional_guidance_scale=2.5, ddim_steps=4)
+    assert rel(out["x0"], g["x0"]) < 1e-4
+    assert torch.equal(out["mask"], torch.from_numpy(g["mask"]))
+    assert rel(out["latent"], g["latent"]) < 1e-4
+    assert rel(out["wave"], g["wave"]) < 1e-4
+
+
+def test_ancestral_oracle_matches_reference_sample():
+    """Ancestral DDPM sampler vs the real LatentDiffusion.sample(timesteps=4) fixture."""
+    from oracle.pipeline import OracleLatentDiffusion
+    g = gold("ancestral_4step_b1")
+    o = OracleLatentDiffusion()
+    torch.manual_seed(cases.E2E_SEED)
+    z, first = o.sample_ancestral(cases.e2e_batch(1), 4)
+    assert rel(first, g["first"]) < 1e-4
+    assert rel(z, g["latent"]) < 1e-4
