@@ -13,10 +13,13 @@
 // pairs with the same +4), which is what makes both products transpose-free.
 #include "common.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace aldm {
 
-template <bool HAS_MASK>
+// QT = 32-query tiles per wave.  With QT = 2 one wave reuses every K / V fragment it loads for 64
+// queries (half the L1/L2 traffic per MFMA); used when the grid still fills the chip.
+template <bool HAS_MASK, int QT>
 __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -27,27 +30,32 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
     const int lh = lane >> 5;
     const int h = blockIdx.y;
     const int b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
     if (q0 >= Lq) return;  // wave-uniform
 
-    // Q fragment: Q[q0 + l31][h*32 + 16*lh + s], pre-scaled (rows past Lq are clamped, never stored)
-    float qf[16];
-    {
-        const int qi = min(q0 + l31, Lq - 1);
+    // Q fragments: Q[q0 + 32*t + l31][h*32 + 16*lh + s], pre-scaled (rows past Lq are clamped, never stored)
+    float qf[QT][16];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = min(q0 + 32 * t + l31, Lq - 1);
         const float* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32 + 16 * lh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(qp + 4 * g);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) qf[4 * g + e] = t[e] * scale;
+            for (int e = 0; e < 4; ++e) qf[t][4 * g + e] = x[e] * scale;
         }
     }
 
-    f32x16 oT;
+    f32x16 oT[QT];
+    float m_run[QT], l_run[QT];  // l_run: this lane's half of the row sum
 #pragma unroll
-    for (int e = 0; e < 16; ++e) oT[e] = 0.f;
-    float m_run = -INFINITY;
-    float l_run = 0.f;  // this lane's half of the row sum
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[t][e] = 0.f;
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+    }
 
     const float* kb = k + (int64_t)b * Lk * ldk + h * 32;
     const float* vb = v + (int64_t)b * Lk * ldv + h * 32;
@@ -75,55 +83,67 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         load_tile(j0);
         // S^T tile = K Q^T: lane (query l31, half lh) gets its query's scores against keys
         // j0 + (r&3) + 8(r>>2) + 4*lh
-        f32x16 st;
+        f32x16 st[QT];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(kraw[s >> 2][s & 3], qf[s], st, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kraw[s >> 2][s & 3], qf[t][s], st[t], 0, 0, 0);
 
-        // masking: out-of-range keys are excluded (-inf); masked keys get -FLT_MAX exactly as
-        // masked_fill_(~(mask == 1), -finfo.max) does in the reference
-        float tmax = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float sv = st[r];
-            if (HAS_MASK) sv = mk[r] != 1.0f ? -FLT_MAX : sv;
-            sv = kj >= Lk ? -INFINITY : sv;
-            st[r] = sv;
-            tmax = fmaxf(tmax, sv);
+        for (int t = 0; t < QT; ++t) {
+            // masking: out-of-range keys are excluded (-inf); masked keys get -FLT_MAX exactly as
+            // masked_fill_(~(mask == 1), -finfo.max) does in the reference
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float sv = st[t][r];
+                if (HAS_MASK) sv = mk[r] != 1.0f ? -FLT_MAX : sv;
+                sv = kj >= Lk ? -INFINITY : sv;
+                st[t][r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run[t], tmax);
+            const float alpha = __expf(m_run[t] - m_new);  // 0 on the first tile (m_run = -inf)
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(st[t][r] - m_new);
+                st[t][r] = pv;
+                psum += pv;
+            }
+            l_run[t] = l_run[t] * alpha + psum;
+            m_run[t] = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oT[t][e] *= alpha;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = __expf(st[r] - m_new);
-            st[r] = pv;
-            psum += pv;
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oT[e] *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            oT = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[r], oT, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                oT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[t][r], oT[t], 0, 0, 0);
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    const int qi = q0 + l31;
-    if (qi < Lq) {
-        float* op = out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 t;
+    for (int t = 0; t < QT; ++t) {
+        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + 32 * t + l31;
+        if (qi < Lq) {
+            float* op = out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = oT[4 * g + e] * inv;
-            *reinterpret_cast<f32x4*>(op + 8 * g) = t;
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
+                *reinterpret_cast<f32x4*>(op + 8 * g) = x;
+            }
         }
     }
 }
@@ -143,13 +163,25 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
     ALDM_CHECK(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
                  reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                "aldm_attention_d32: q/k/out must be 16-byte aligned");
-    dim3 grid(cdiv(Lq, 128), heads, B);
-    if (mask)
-        hipLaunchKernelGGL(attention_d32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out,
-                           Lq, Lk, ldq, ldk, ldv, ldo, mask, scale);
-    else
-        hipLaunchKernelGGL(attention_d32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, out,
-                           Lq, Lk, ldq, ldk, ldv, ldo, mask, scale);
+    hipStream_t st = (hipStream_t)stream;
+    // 64 queries per wave when that grid still gives every CU two blocks
+    static const int env_qt = [] {
+        const char* e = getenv("ALDM_ATTN_QT");  // A/B override: 1 or 2 query tiles per wave
+        return e ? atoi(e) : 0;
+    }();
+    const bool qt2 = env_qt ? env_qt == 2 : (int64_t)cdiv(Lq, 256) * heads * B >= 512;
+    dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
+#define ALDM_ATTN(M_, Q_)                                                                                \
+    hipLaunchKernelGGL((attention_d32_kernel<M_, Q_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
+                       ldk, ldv, ldo, mask, scale)
+    if (mask) {
+        if (qt2) ALDM_ATTN(true, 2);
+        else ALDM_ATTN(true, 1);
+    } else {
+        if (qt2) ALDM_ATTN(false, 2);
+        else ALDM_ATTN(false, 1);
+    }
+#undef ALDM_ATTN
     ALDM_LAUNCH_CHECK("aldm_attention_d32");
     return 0;
 }

@@ -13,7 +13,6 @@ int igemm_launch_pre1(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p
 int igemm_launch_pre2(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_pre3(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_pre4(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre5(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -169,13 +168,6 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.pre_scale == nullptr ||
                    ((reinterpret_cast<uintptr_t>(d.pre_scale) | reinterpret_cast<uintptr_t>(d.pre_shift)) & 15) == 0,
                "aldm_igemm: pre_scale/pre_shift must be 16-byte aligned");
-    if (d.pre_rowstats != nullptr) {
-        ALDM_CHECK(d.pre_scale && d.pre_shift && d.pre_act == ALDM_ACT_NONE && d.C2 == 0 && d.KH == 1 && d.KW == 1 &&
-                       d.SH == 1 && d.SW == 1 && d.PH == 0 && d.PW == 0 && d.up_h == 1 && d.up_w == 1 &&
-                       d.OH == d.H && d.OW == d.W,
-                   "aldm_igemm: the row-norm prologue needs a plain row-major GEMM (1x1, no stride/pad/upsample/"
-                   "concat) with gamma/beta in pre_scale/pre_shift");
-    }
     const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
     ALDM_CHECK(d.epi_mode == ALDM_EPI_PLAIN || geglu, "aldm_igemm: unknown epi_mode %d", d.epi_mode);
     if (geglu) {
@@ -227,12 +219,15 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu;
     const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
     int splits = 1;
-    if (g_force_bm) {
-        BM = g_force_bm;
-        BN = g_force_bn;
-        ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm_force: unsupported tile %dx%d", BM, BN);
-        ALDM_CHECK(!geglu || BN == 128, "aldm_igemm_force: the GEGLU epilogue needs a 128-column tile");
-        if (g_force_splits > 0 && can_split) splits = g_force_splits;
+    // explicit choice: thread-local override (tools/tests) first, then the descriptor's tuned hint
+    const int f_bm = g_force_bm ? g_force_bm : d.hint_bm, f_bn = g_force_bm ? g_force_bn : d.hint_bn;
+    const int f_sp = g_force_bm ? g_force_splits : d.hint_splits;
+    if (f_bm) {
+        BM = f_bm;
+        BN = f_bn;
+        ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm: unsupported forced/hinted tile %dx%d", BM, BN);
+        ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: the GEGLU epilogue needs a 128-column tile");
+        if (f_sp > 0 && can_split && nk / f_sp >= 1) splits = f_sp;
     } else if (d.N <= 32 && !geglu) {
         BM = 128;
         BN = 32;
@@ -310,8 +305,7 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits, (unsigned)d.batch);
     hipStream_t st = (hipStream_t)stream;
     int pre;
-    if (d.pre_rowstats != nullptr) pre = PRE_ROWNORM;
-    else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_NONE;
+    if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_NONE;
     else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_AFFINE;
     else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_SILU) pre = PRE_AFFINE_SILU;
     else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) pre = PRE_LRELU;
@@ -321,7 +315,6 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
         case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, grid, st, p); break;
         case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, grid, st, p); break;
         case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, grid, st, p); break;
-        case PRE_ROWNORM: rc = igemm_launch_pre5(BM, BN, grid, st, p); break;
         default: rc = igemm_launch_pre4(BM, BN, grid, st, p); break;
     }
     if (rc) {

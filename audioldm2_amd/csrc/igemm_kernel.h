@@ -35,7 +35,7 @@ struct IgemmK {
     int rb_ld;                 // row-bias pitch
 };
 
-enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4, PRE_ROWNORM = 5 };
+enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4 };
 
 constexpr int BK = 32;
 constexpr int KG = BK / 4;
@@ -163,18 +163,6 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     const int b_skg = packed ? tid / BN : akg, b_skgs = packed ? stepb : 0;
     const int b_sc = packed ? tid % BN : ar0, b_scs = packed ? 0 : 32;
 
-    // PRE_ROWNORM (LayerNorm fused into the consuming GEMM, attention.py:393-395,406-410): the rows this
-    // thread gathers are fixed for the whole K loop, so their (mean, rstd) are loaded once
-    float rn_mu[PRE == PRE_ROWNORM ? PA : 1], rn_rs[PRE == PRE_ROWNORM ? PA : 1];
-    if constexpr (PRE == PRE_ROWNORM) {
-#pragma unroll
-        for (int pp = 0; pp < PA; ++pp) {
-            const int m = min(m0 + ar0 + 32 * pp, p.M - 1);
-            rn_mu[pp] = d.pre_rowstats[2 * (int64_t)m];
-            rn_rs[pp] = d.pre_rowstats[2 * (int64_t)m + 1];
-        }
-    }
-
     // one in-flight k-tile of this thread's global loads
     constexpr bool AFF = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC;
     struct Stage {
@@ -202,13 +190,6 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
             const int64_t off = ok ? (int64_t)pix * pitch + c : 0;
             r.ra[pp] = *reinterpret_cast<const f32x4*>(src + off);
             r.avalid |= (ok ? 1u : 0u) << pp;
-            if constexpr (PRE == PRE_ROWNORM) {
-                if (pp == 0) {  // gamma / beta of this thread's 4 channels (same for every row pass)
-                    const int cc = kval ? t_ci : 0;
-                    r.rsc[0] = *reinterpret_cast<const f32x4*>(d.pre_scale + cc);
-                    r.rsh[0] = *reinterpret_cast<const f32x4*>(d.pre_shift + cc);
-                }
-            }
             if constexpr (AFF) {
                 if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
                     const int64_t so = ok ? (int64_t)a_b[pp] * p.Cin + t_ci : 0;
@@ -238,7 +219,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     };
 
     // ---- commit = operand prologue on the loaded registers + LDS stores ----
-    constexpr bool ELEMWISE = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_LRELU || PRE == PRE_ROWNORM;
+    constexpr bool ELEMWISE = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_LRELU;
     auto xform_elem = [&](Stage& r, int pp, int c) {  // one component, in place
         float v = r.ra[pp][c];
         if constexpr (PRE == PRE_AFFINE) {
@@ -247,8 +228,6 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
             v = silu_fast(v * r.rsc[pp][c] + r.rsh[pp][c]);
         } else if constexpr (PRE == PRE_LRELU) {
             v = v > 0.0f ? v : v * d.pre_slope;
-        } else if constexpr (PRE == PRE_ROWNORM) {
-            v = (v - rn_mu[pp]) * rn_rs[pp] * r.rsc[0][c] + r.rsh[0][c];  // = layernorm_kernel's op order
         }
         r.ra[pp][c] = v;
     };

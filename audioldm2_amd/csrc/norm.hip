@@ -157,44 +157,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// ---- LayerNorm statistics only (the apply is fused into the consuming GEMM's operand gather) ----
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x,
-                                                        float* __restrict__ stats, int M, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int C4 = C >> 2;
-    const float* xr = x + (int64_t)row * C;
-    f32x4 v[LN_MAXV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 < C4) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 < C4) {
-            const f32x4 dlt = v[i] - mean;
-            q += (dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    if (lane == 0) {
-        stats[2 * (int64_t)row] = mean;
-        stats[2 * (int64_t)row + 1] = 1.0f / sqrtf(q / (float)C + eps);
-    }
-}
-
 // ---- row softmax (VAE mid attention, 4096-wide rows): one block per row, row staged in LDS ----
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
                                                            float* __restrict__ y, int N,
@@ -278,16 +240,6 @@ extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const floa
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, y, M,
                        C, gamma, beta, eps);
     ALDM_LAUNCH_CHECK("aldm_layernorm");
-    return 0;
-}
-
-extern "C" int aldm_row_stats(const float* x, float* stats, int M, int C, float eps, void* stream) {
-    ALDM_CHECK(x && stats && M > 0, "aldm_row_stats: bad args");
-    ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "aldm_row_stats: C=%d must be a multiple of 4 and <= %d", C,
-               256 * LN_MAXV);
-    hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, stats, M, C,
-                       eps);
-    ALDM_LAUNCH_CHECK("aldm_row_stats");
     return 0;
 }
 

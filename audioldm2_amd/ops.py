@@ -89,7 +89,27 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
     e1.record()
     shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch, sp.value)
-    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape))
+    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape, _kernel_name(d, bm.value, bn.value)))
+
+
+def _pre_mode(d: IgemmDesc) -> int:
+    """Prologue mode a descriptor dispatches to (PRE_* of csrc/igemm_kernel.h)."""
+    if not d.pre_scale and d.pre_act == ACT_NONE:
+        return 0
+    if d.pre_scale and d.pre_act == ACT_NONE:
+        return 1
+    if d.pre_scale and d.pre_act == ACT_SILU:
+        return 2
+    if not d.pre_scale and d.pre_act == ACT_LRELU:
+        return 3
+    return 4
+
+
+def _kernel_name(d: IgemmDesc, bm: int, bn: int) -> str:
+    """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
+    (igemm_kernel<BM, BN, WM, WN, PRE>)."""
+    wm, wn = (4, 1) if bn == 32 else (2, 2)
+    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {_pre_mode(d)}>"
 
 
 def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0) -> None:
@@ -133,7 +153,7 @@ def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
     return pack_conv(weight.detach()[perm], None if bias is None else bias.detach()[perm])
 
 
-def linear_geglu(x: torch.Tensor, pw: Packed, rownorm=None) -> torch.Tensor:
+def linear_geglu(x: torch.Tensor, pw: Packed) -> torch.Tensor:
     """y = value * gelu_erf(gate) with [value | gate] = x @ W^T + b fused into the GEMM epilogue
     (attention.py:37-45); pw from pack_geglu.  x: [..., Cin] -> [..., N/2]."""
     _chk(x, "linear_geglu.x")
@@ -148,10 +168,6 @@ def linear_geglu(x: torch.Tensor, pw: Packed, rownorm=None) -> torch.Tensor:
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
     d.bias = _p(pw.bias); d.out = out.data_ptr(); d.ldo = pw.N // 2; d.alpha = 1.0
     d.epi_mode = _l.EPI_GEGLU; d.batch = 1
-    if rownorm is not None:
-        st, ga, be = rownorm
-        assert st.shape == (M, 2) and ga.numel() == pw.Cin and be.numel() == pw.Cin
-        d.pre_rowstats = st.data_ptr(); d.pre_scale = ga.data_ptr(); d.pre_shift = be.data_ptr()
     _igemm(d, "igemm(geglu)")
     return out
 
@@ -180,8 +196,7 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
          act: int = ACT_NONE, act_slope: float = 0.0, alpha: float = 1.0,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
          remap: Optional[Tuple[int, int, int]] = None,
-         use_pw_bias: bool = True,
-         rownorm: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+         use_pw_bias: bool = True) -> torch.Tensor:
     """Implicit-GEMM convolution (aldm_igemm).  x: [B, H, W, C1] (+ x2: [B, H, W, C2] concatenated
     along C).  Returns [B, OH, OW, N] (or the remapped [B, 1, out_len, N])."""
     _chk(x, "conv.x")
@@ -222,11 +237,6 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.OH = OH; d.OW = OW
     if pre is not None:
         d.pre_scale = pre[0].data_ptr(); d.pre_shift = pre[1].data_ptr()
-    if rownorm is not None:  # fused LayerNorm: (stats [M, 2], gamma [C], beta [C])
-        assert pre is None and pre_act == ACT_NONE and x2 is None
-        st, ga, be = rownorm
-        assert st.shape == (B * OH * OW, 2) and ga.numel() == C1 and be.numel() == C1
-        d.pre_rowstats = st.data_ptr(); d.pre_scale = ga.data_ptr(); d.pre_shift = be.data_ptr()
     d.pre_act = pre_act; d.pre_slope = pre_slope
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
     d.K = pw.K; d.N = N
@@ -332,17 +342,6 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups
                                       gamma.data_ptr(), beta.data_ptr(), ss[0].data_ptr(),
                                       ss[1].data_ptr(), ws.data_ptr(), _stream()), "groupnorm_stats")
     return ss[0], ss[1]
-
-
-def row_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    """LayerNorm statistics of [..., C] rows -> [M, 2] = {mean, rstd}; the normalisation itself is fused
-    into the consuming GEMM (conv/linear/linear_geglu `rownorm=(stats, gamma, beta)`)."""
-    _chk(x, "row_stats.x")
-    Cc = x.shape[-1]
-    M = x.numel() // Cc
-    st = torch.empty((M, 2), device=x.device, dtype=torch.float32)
-    _l.check(_l.load().aldm_row_stats(x.data_ptr(), st.data_ptr(), M, Cc, eps, _stream()), "row_stats")
-    return st
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):

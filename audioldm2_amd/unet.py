@@ -194,25 +194,23 @@ class BasicTransformerBlock(nn.Module):
         """h: [B, L, C] tokens.  attention.py:406-410 (mask is ignored when context is None: :400-404)."""
         pk = self._prepare()
         C = self.dim
-        # the three LayerNorms (attention.py:393-395) are fused into the GEMMs that consume them:
-        # one statistics kernel per norm, normalisation applied in the operand gather
-        ln1 = (ops.row_stats(h), *pk["ln"][0])
-        qkv = ops.linear(h, pk["qkv1"], rownorm=ln1)
+        n = ops.layernorm(h, *pk["ln"][0])
+        qkv = ops.linear(n, pk["qkv1"])
         a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
         h = ops.linear(a, pk["out1"], res=h)
-        ln2 = (ops.row_stats(h), *pk["ln"][1])
+        n = ops.layernorm(h, *pk["ln"][1])
         if context is None:
             if pk["qkv2"] is None:
                 raise RuntimeError("attn2 was built with a context_dim but no context was provided")
-            qkv = ops.linear(h, pk["qkv2"], rownorm=ln2)
+            qkv = ops.linear(n, pk["qkv2"])
             a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
         else:
-            q = ops.linear(h, pk["q2"], rownorm=ln2)
+            q = ops.linear(n, pk["q2"])
             kv = self._context_kv(context, pk)
             a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads, mask=mask)
         h = ops.linear(a, pk["out2"], res=h)
-        ln3 = (ops.row_stats(h), *pk["ln"][2])
-        g = ops.linear_geglu(h, pk["ff1"], rownorm=ln3)  # LN + Linear(C, 8C) + x*gelu(gate) in one GEMM
+        n = ops.layernorm(h, *pk["ln"][2])
+        g = ops.linear_geglu(n, pk["ff1"])  # Linear(C, 8C) + x*gelu(gate) in one GEMM (attention.py:37-45)
         return ops.linear(g, pk["ff2"], res=h)
 
 

@@ -68,13 +68,15 @@ def roofline_probe(ld, batch, B):
     finally:
         ops.PROFILE = None
     agg = {}
-    for what, bm, bn, fl, e0, e1, _shape in prof:
-        a = agg.setdefault((bm, bn), [0, 0.0, 0.0])
+    for what, bm, bn, fl, e0, e1, shape, kname in prof:
+        a = agg.setdefault(kname, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += fl
         a[2] += e0.elapsed_time(e1) * 1e-3
+        M, N, K, taps = shape[0], shape[1], shape[2], shape[3]
+        a[3] += 4.0 * (M * K / taps + K * N + M * N) * shape[7]  # read A once + W once, write out once
     dom = max(agg.items(), key=lambda kv: kv[1][2])
-    (bm, bn), (n, fl, sec) = dom
+    kname, (n, fl, sec, minb) = dom
     achieved = fl / sec / 1e12
     tot_fl = sum(v[1] for v in agg.values())
     tot_s = sum(v[2] for v in agg.values())
@@ -84,17 +86,17 @@ def roofline_probe(ld, batch, B):
     if os.path.exists(TRAFFIC_JSON):
         with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
-        ent = tj.get("kernels", {}).get(f"igemm_kernel<{bm}, {bn}>")
+        ent = tj.get("kernels", {}).get(kname)
         if ent:
             traffic = ent["hbm_bytes_per_launch"]
             traffic_src = {"file": "profiles/r01_pmc_traffic.json", "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
-                           "write_bytes_per_launch": ent["write_bytes_per_launch"],
-                           "algorithmic_min_bytes_per_launch": ent.get("note")}
+                           "write_bytes_per_launch": ent["write_bytes_per_launch"]}
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": f"aldm::igemm_kernel<{bm},{bn}>", "launches_per_unet_pass": n,
+        "algorithmic_bytes_per_launch": round(minb / n),
+        "kernel": "aldm::" + kname, "launches_per_unet_pass": n,
         "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
         "all_igemm_tflops": round(tot_fl / tot_s / 1e12, 2),
         "all_igemm_launches": sum(v[0] for v in agg.values()),

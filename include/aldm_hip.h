@@ -114,11 +114,10 @@ typedef struct aldm_igemm_desc {
     float* ws;             /* optional split-K workspace (caller-owned scratch, see
                               aldm_igemm_ws_floats); NULL or too small => no split-K            */
     int64_t ws_floats;     /* capacity of ws in floats                                          */
-    /* ABI v3: LayerNorm fused into the consuming GEMM (attention.py:393-395 -> :335-342 / :40).
-       pre_rowstats: [M][2] = {mean, rstd} per GEMM row from aldm_row_stats; pre_scale / pre_shift
-       then hold gamma / beta [K] and a = (a - mean[m]) * rstd[m] * gamma[k] + beta[k].  Plain
-       row-major GEMMs only (1x1, no stride/pad/upsample/concat).                               */
-    const float* pre_rowstats;
+    /* ABI v3: tuned launch configuration for this shape (0 = pick with the built-in cost model):
+       block tile hint_bm x hint_bn in {128x128,128x64,64x128,64x64,128x32} and split-K factor.
+       audioldm2_amd/tuning/ (JSON) holds the table measured on MI355X (tools/igemm_autotune.py).  */
+    int32_t hint_bm, hint_bn, hint_splits, reserved1;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -156,9 +155,6 @@ int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1,
                          int G, float eps, const float* gamma, const float* beta,
                          float* scale, float* shift, float* ws, void* stream);
 int64_t aldm_gn_ws_floats(int B, int P, int C, int G);
-/* Per-row LayerNorm statistics of [M, C]: stats[m] = {mean, 1/sqrt(var + eps)} (exact two-pass,
- * biased variance), consumed by aldm_igemm's pre_rowstats prologue.                            */
-int aldm_row_stats(const float* x, float* stats, int M, int C, float eps, void* stream);
 /* LayerNorm over the last dim of [M, C] (attention.py:393-395), eps 1e-5                   */
 int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                    const float* beta, float eps, void* stream);

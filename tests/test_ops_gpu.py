@@ -172,24 +172,6 @@ def test_linear_geglu_fused(ops, M, C, inner):
     assert rel_err(y, ref) < GEMM_TOL
 
 
-@pytest.mark.parametrize("M,C,N", [(1024, 256, 768), (300, 384, 384), (70, 640, 1920)])
-def test_linear_with_fused_layernorm(ops, M, C, N):
-    """LayerNorm (attention.py:393-395) fused into the consuming Linear's operand gather (row statistics
-    kernel + PRE_ROWNORM) vs F.layer_norm -> F.linear, and bitwise vs the unfused HIP LayerNorm + linear."""
-    x = torch.randn(M, C, generator=g(1)) * 3 + 0.7
-    w = torch.randn(N, C, generator=g(2)) / math.sqrt(C)
-    b = torch.randn(N, generator=g(3))
-    ga, be = torch.randn(C, generator=g(4)), torch.randn(C, generator=g(5))
-    ref = F.linear(F.layer_norm(x, (C,), ga, be, 1e-5), w, b)
-    pw = ops.pack_conv(w, b)
-    xs = x.cuda()
-    st = ops.row_stats(xs)
-    y = ops.linear(xs, pw, rownorm=(st, ga.cuda(), be.cuda()))
-    assert rel_err(y, ref) < GEMM_TOL
-    y2 = ops.linear(ops.layernorm(xs, ga.cuda(), be.cuda()), pw)
-    assert torch.equal(y, y2), "fused and unfused LayerNorm must agree bit for bit (same operation order)"
-
-
 def test_conv_upsample_nearest(ops):
     B, C, H, W = 2, 64, 8, 4
     x = torch.randn(B, C, H, W, generator=g(1))

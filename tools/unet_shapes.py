@@ -31,7 +31,7 @@ def main():
         ld.apply_model_cfg(x, t2, cond, uncond)
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
-        for what, bm, bn, fl, e0, e1, shape in prof:
+        for what, bm, bn, fl, e0, e1, shape, _kn in prof:
             a = agg.setdefault((shape, bm, bn), [0, 0.0, 0.0])
             a[0] += 1
             a[1] += fl
