@@ -164,12 +164,14 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
                  reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                "aldm_attention_d32: q/k/out must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    // 64 queries per wave when that grid still gives every CU two blocks
+    // 64 queries per wave (K/V fragments reused twice) when that grid still gives every CU two blocks and
+    // there are enough keys to amortise the doubled prologue: 1024x1024 self-attention 205 -> 195 us,
+    // 1024x32 cross-attention 12.0 -> 13.8 us on MI355X (tools/gpu/run9.sh)
     static const int env_qt = [] {
         const char* e = getenv("ALDM_ATTN_QT");  // A/B override: 1 or 2 query tiles per wave
         return e ? atoi(e) : 0;
     }();
-    const bool qt2 = env_qt ? env_qt == 2 : (int64_t)cdiv(Lq, 256) * heads * B >= 512;
+    const bool qt2 = env_qt ? env_qt == 2 : (Lk >= 256 && (int64_t)cdiv(Lq, 256) * heads * B >= 512);
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
 #define ALDM_ATTN(M_, Q_)                                                                                \
     hipLaunchKernelGGL((attention_d32_kernel<M_, Q_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \

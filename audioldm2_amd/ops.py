@@ -6,6 +6,8 @@ Layout convention: activations are channels-last fp32, `[B, H, W, C]` (2-D) or `
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -75,8 +77,41 @@ def _workspace(lib, d: IgemmDesc, device) -> None:
     d.ws_floats = buf.numel()
 
 
+# ---- tuned launch configurations -------------------------------------------------------------------
+# audioldm2_amd/tuning/mi355x_igemm.json: {(geometry key): [BM, BN, splits]} measured on MI355X by
+# tools/igemm_autotune.py for the shapes of the shipped model configs; everything else (and everything
+# when ALDM_NO_TUNING=1) uses the library's built-in cost model.  Only speed and the (deterministic)
+# fp32 summation order depend on the choice.
+_TUNE_FIELDS = ("B", "H", "W", "C1", "C2", "pix1", "up_h", "up_w", "KH", "KW", "SH", "SW", "PH", "PW", "DH", "DW",
+                "OH", "OW", "N", "b_mode", "batch", "epi_mode", "out_mul")
+_TUNED = None
+TUNE_LOG = None  # when a list: every launch's geometry key is appended (tools/igemm_autotune.py)
+
+
+def tune_key(d: IgemmDesc) -> str:
+    return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}"
+
+
+def _tuned_table():
+    global _TUNED
+    if _TUNED is None:
+        _TUNED = {}
+        if os.environ.get("ALDM_NO_TUNING", "0") != "1":
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "mi355x_igemm.json")
+            if os.path.exists(path):
+                with open(path) as f:
+                    _TUNED = {k: v[:3] for k, v in json.load(f)["entries"].items()}
+    return _TUNED
+
+
 def _igemm(d: IgemmDesc, what: str, device=None):
     lib = _l.load()
+    key = tune_key(d)
+    if TUNE_LOG is not None:
+        TUNE_LOG.append(key)
+    hint = _tuned_table().get(key)
+    if hint is not None:
+        d.hint_bm, d.hint_bn, d.hint_splits = hint
     _workspace(lib, d, device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     if PROFILE is None:
         _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)

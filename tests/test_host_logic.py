@@ -125,3 +125,24 @@ def test_config_and_conditioning_routing():
     f = FixedCond("film", 512, device="cpu")
     y, ctxs, _ = DiffusionWrapper.route({"film_clap_cond1": f(batch["text"])})
     assert tuple(y.shape) == (4, 512) and ctxs == []
+
+
+def test_igemm_tuning_table_is_wellformed():
+    """audioldm2_amd/tuning/mi355x_igemm.json (measured launch configurations): keys follow
+    ops._TUNE_FIELDS + pre_mode, values name supported tiles; ops.tune_key spells keys the same way."""
+    import json
+    from audioldm2_amd import lib, ops
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audioldm2_amd", "tuning",
+                        "mi355x_igemm.json")
+    with open(path) as f:
+        t = json.load(f)
+    assert t["fields"] == list(ops._TUNE_FIELDS) + ["pre_mode"]
+    tiles = {(128, 128), (128, 64), (64, 128), (64, 64), (128, 32)}
+    assert len(t["entries"]) > 0
+    for k, v in t["entries"].items():
+        parts = k.split(",")
+        assert len(parts) == len(t["fields"]) and all(p.lstrip("-").isdigit() for p in parts)
+        assert (v[0], v[1]) in tiles and 1 <= v[2] <= 16
+    d = lib.IgemmDesc()
+    d.B, d.H, d.W, d.C1, d.KH, d.KW, d.N = 1, 1, 77, 64, 1, 1, 32
+    assert len(ops.tune_key(d).split(",")) == len(t["fields"])
