@@ -8,11 +8,11 @@
 namespace aldm {
 
 // per-prologue launchers (igemm_pre*.hip)
-int igemm_launch_pre0(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre1(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre2(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre3(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre4(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre0(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre1(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre2(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre3(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre4(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -115,12 +115,13 @@ static int log2_exact(int v) {
 
 using namespace aldm;
 
-static thread_local int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+static thread_local int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0, g_force_kgroups = 0;
 
-extern "C" void aldm_igemm_force(int bm, int bn, int splits) {
+extern "C" void aldm_igemm_force(int bm, int bn, int splits, int kgroups) {
     g_force_bm = bm;
     g_force_bn = bn;
     g_force_splits = splits;
+    g_force_kgroups = kgroups;
 }
 
 static bool tile_supported(int BM, int BN) {
@@ -200,17 +201,18 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     // 10k cycles + (splits + 1) * M * N * 4 B at 2000 B/cycle.
     auto occ_of = [](int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : ((bm * bn >= 64 * 128 || bn == 32) ? 3 : 4); };
     const double pre_w = (d.pre_scale != nullptr || d.pre_act != ALDM_ACT_NONE) ? 1.5 : 1.0;
-    auto cost_of = [&](int bm, int bn, int sp, int* sp_eff) -> double {
+    auto cost_of = [&](int bm, int bn, int sp, int kg, int* sp_eff) -> double {
         const int kt = cdiv(nk, sp);
         sp = cdiv(nk, kt);
         *sp_eff = sp;
         const double blocks = (double)cdiv64(Mz, bm) * cdiv(d.N, bn) * d.batch * sp;
         const double L = (double)kt * bm * bn / 4.0;
-        const int o = occ_of(bm, bn);
-        const double S = 300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32), F = 4000.0;
+        const int o = kg == 2 ? 2 : occ_of(bm, bn);  // 512-thread blocks: two per CU
+        const double S = 300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32), F = 4000.0 + (kg == 2 ? 600.0 : 0.0);
         const int64_t nb = (int64_t)((blocks + 255.0) / 256.0);
         const int64_t full = nb / o, last = nb - full * o;
-        const double one = L + kt * S + F;
+        // critical path of one wave group: it multiplies every kg-th k-tile
+        const double one = (double)cdiv(kt, kg) * ((double)bm * bn / 4.0 + S) + F;
         double T = full * std::max(one, o * L);
         if (last) T += std::max(one, last * L);
         if (sp > 1) T += 10000.0 + (double)(sp + 1) * Mz * d.N * d.batch * 4.0 / 2000.0;
@@ -218,16 +220,21 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     };
     const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu;
     const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
-    int splits = 1;
+    int splits = 1, kgroups = 1;
     // explicit choice: thread-local override (tools/tests) first, then the descriptor's tuned hint
     const int f_bm = g_force_bm ? g_force_bm : d.hint_bm, f_bn = g_force_bm ? g_force_bn : d.hint_bn;
     const int f_sp = g_force_bm ? g_force_splits : d.hint_splits;
+    const int f_kg = g_force_bm ? g_force_kgroups : d.hint_kgroups;
     if (f_bm) {
         BM = f_bm;
         BN = f_bn;
         ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm: unsupported forced/hinted tile %dx%d", BM, BN);
         ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: the GEGLU epilogue needs a 128-column tile");
         if (f_sp > 0 && can_split && nk / f_sp >= 1) splits = f_sp;
+        if (f_kg == 2) {
+            ALDM_CHECK(BM == 64 && BN == 64, "aldm_igemm: two wave groups exist for the 64x64 tile only");
+            kgroups = 2;
+        }
     } else if (d.N <= 32 && !geglu) {
         BM = 128;
         BN = 32;
@@ -243,14 +250,18 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             for (int si = 0; si < 8; ++si) {
                 const int sp = sps[si];
                 if (sp > 1 && (!can_split || !have_ws || nk / sp < 3)) break;
-                int spe;
-                const double t = cost_of(bm, bn, sp, &spe);
-                if (spe > 1 && (int64_t)d.batch * spe * Mz * d.N > d.ws_floats) continue;
-                if (t < best) {
-                    best = t;
-                    BM = bm;
-                    BN = bn;
-                    splits = spe;
+                for (int kg = 1; kg <= ((bm == 64 && bn == 64) ? 2 : 1); ++kg) {
+                    int spe;
+                    const double t = cost_of(bm, bn, sp, kg, &spe);
+                    if (spe > 1 && (int64_t)d.batch * spe * Mz * d.N > d.ws_floats) continue;
+                    if (kg == 2 && cdiv(nk, spe) < 4) continue;
+                    if (t < best) {
+                        best = t;
+                        BM = bm;
+                        BN = bn;
+                        splits = spe;
+                        kgroups = kg;
+                    }
                 }
             }
         }
@@ -269,10 +280,12 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         }
     }
     p.splits = splits;
+    p.kgroups = kgroups;
     return 0;
 }
 
-extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int64_t* flops, int* splits) {
+extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int64_t* flops, int* splits,
+                               int* kgroups) {
     IgemmK p;
     int BM, BN;
     const int rc = igemm_prepare(dd, p, BM, BN);
@@ -281,6 +294,7 @@ extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int6
     if (bn) *bn = BN;
     if (flops) *flops = 2ll * p.M * p.d.N * p.d.K * p.d.batch;
     if (splits) *splits = p.splits;
+    if (kgroups) *kgroups = p.kgroups;
     return 0;
 }
 
@@ -311,11 +325,11 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) pre = PRE_LRELU;
     else pre = PRE_GENERIC;
     switch (pre) {
-        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, grid, st, p); break;
-        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, grid, st, p); break;
-        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, grid, st, p); break;
-        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, grid, st, p); break;
-        default: rc = igemm_launch_pre4(BM, BN, grid, st, p); break;
+        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, p.kgroups, grid, st, p); break;
+        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, p.kgroups, grid, st, p); break;
+        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, p.kgroups, grid, st, p); break;
+        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, p.kgroups, grid, st, p); break;
+        default: rc = igemm_launch_pre4(BM, BN, p.kgroups, grid, st, p); break;
     }
     if (rc) {
         set_error("aldm_igemm: no kernel for tile %dx%d", BM, BN);

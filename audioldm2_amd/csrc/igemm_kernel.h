@@ -32,6 +32,7 @@ struct IgemmK {
     aldm_igemm_desc d;
     int Cin, M, OHW, HV, WV, shh, shw, Kg, Npad, tiles_m, tiles_n;
     int splits, kt_per_split;  // split-K: k-tiles [s*kt_per_split, ...) per blockIdx.y
+    int kgroups;               // wave groups per block (1 or 2, see igemm_kernel)
     int rb_ld;                 // row-bias pitch
 };
 
@@ -68,8 +69,15 @@ constexpr int igemm_min_blocks(int BM, int BN) {
 // Measured and rejected (profiles/r01_igemm_pipeline_variants_ab.txt): folding commit() into the
 // second half's MFMAs with sched_barrier fences, and a second register stage of global loads for the
 // 64x64 tile — both within +-2 % of this simpler pipeline on the UNet's shapes.
-template <int BM, int BN, int WM, int WN, int PRE>
-__global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(const IgemmK p) {
+//
+// KGRP = wave groups per block.  KGRP = 2 (512 threads): two 4-wave groups work on the SAME output tile,
+// each with its own LDS double buffer, group g taking k-tiles g, g+2, ...; their accumulators are added
+// through LDS before the epilogue (fixed order: deterministic).  For launches with fewer than two blocks
+// per CU this puts two waves on every SIMD, so one group's LDS/barrier/address turnaround (≈1700 cycles
+// per k-tile when alone, measured) hides behind the other group's MFMAs — an in-block split-K with no
+// workspace and no reduce kernel.
+template <int BM, int BN, int WM, int WN, int PRE, int KGRP>
+__global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN)) void igemm_kernel(const IgemmK p) {
     constexpr int MT = BM / (32 * WM);
     constexpr int NT = BN / (32 * WN);
     constexpr int PA = BM / 32;  // A-loader passes (32 rows x 8 k-groups per pass)
@@ -78,12 +86,13 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     // one raw LDS buffer: A/B double buffers during the K loop, per-wave output staging afterwards
     constexpr int A_F4 = 2 * KG * (BM + 1);
     constexpr int B_F4 = 2 * KG * (BN + 1);
-    __shared__ f32x4 smem[A_F4 + B_F4];
-    f32x4 (*As)[KG][BM + 1] = reinterpret_cast<f32x4 (*)[KG][BM + 1]>(&smem[0]);
-    f32x4 (*Bs)[KG][BN + 1] = reinterpret_cast<f32x4 (*)[KG][BN + 1]>(&smem[A_F4]);
+    __shared__ f32x4 smem[KGRP * (A_F4 + B_F4)];
+    const int grp = KGRP == 1 ? 0 : (int)(threadIdx.x >> 8);
+    f32x4 (*As)[KG][BM + 1] = reinterpret_cast<f32x4 (*)[KG][BM + 1]>(&smem[grp * (A_F4 + B_F4)]);
+    f32x4 (*Bs)[KG][BN + 1] = reinterpret_cast<f32x4 (*)[KG][BN + 1]>(&smem[grp * (A_F4 + B_F4) + A_F4]);
 
     const aldm_igemm_desc& d = p.d;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;  // position inside the 4-wave group
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     // incremental (kh, kw, ci) of this thread's k = kt*BK + 4*akg
     int t_ci, t_kh, t_kw;
     {
-        const int k = kt0 * BK + 4 * akg;
+        const int k = (kt0 + grp) * BK + 4 * akg;  // group g starts at k-tile kt0 + g
         const int tap = k / p.Cin;
         t_ci = k - tap * p.Cin;
         t_kh = tap / d.KW;
@@ -198,8 +207,8 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
                 }
             }
         }
-        // advance (kh, kw, ci) by one k-tile
-        t_ci += BK;
+        // advance (kh, kw, ci) to this group's next k-tile
+        t_ci += BK * KGRP;
         while (t_ci >= p.Cin) {
             t_ci -= p.Cin;
             if (++t_kw == d.KW) {
@@ -294,22 +303,27 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
         }
     };
     if (kt0 < kt1) {
+        // group g multiplies k-tiles kt0 + g + it*KGRP; every group runs the same number of iterations
+        // (and barriers), an iteration without a tile only synchronises
+        const int n_it = (kt1 - kt0 + KGRP - 1) / KGRP;
+        auto tile_of = [&](int it) { return kt0 + grp + it * KGRP; };
         Stage r0;
-        issue_loads(r0, kt0);
-        commit(r0, 0);
+        if (tile_of(0) < kt1) {
+            issue_loads(r0, tile_of(0));
+            commit(r0, 0);
+        }
         __syncthreads();
         int buf = 0;
-        for (int kt = kt0; kt + 1 < kt1; ++kt) {
-            issue_loads(r0, kt + 1);
-            mma_half(buf, 0);
+        for (int it = 0; it < n_it; ++it) {
+            const bool cur = tile_of(it) < kt1, nxt = tile_of(it + 1) < kt1;
+            if (nxt) issue_loads(r0, tile_of(it + 1));
+            if (cur) mma_half(buf, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use behind half the MFMAs
-            commit(r0, buf ^ 1);
-            mma_half(buf, 1);
-            __syncthreads();
+            if (nxt) commit(r0, buf ^ 1);
+            if (cur) mma_half(buf, 1);
+            if (it + 1 < n_it) __syncthreads();
             buf ^= 1;
         }
-        mma_half(buf, 0);  // last tile: nothing left to stage
-        mma_half(buf, 1);
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -326,6 +340,28 @@ __global__ __launch_bounds__(256, igemm_min_blocks(BM, BN)) void igemm_kernel(co
     constexpr int ITC = IT < 4 ? IT : 4;  // ... processed ITC at a time
     static_assert(4 * 32 * SP * 4 <= (A_F4 + B_F4) * 16, "staging must fit the K-loop LDS");
     __syncthreads();  // every wave is done reading As/Bs
+    if constexpr (KGRP == 2) {
+        // add the two groups' accumulators: group 1 parks its registers in LDS (lane-linear, conflict
+        // free, behind the transpose staging area), group 0 adds them and runs the epilogue alone
+        static_assert(4 * 32 * SP * 4 + 4 * MT * NT * 16 * 64 * 4 <= KGRP * (A_F4 + B_F4) * 16, "reduction area");
+        float* red = reinterpret_cast<float*>(&smem[0]) + 4 * 32 * SP + wave * (MT * NT * 16 * 64) + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((i * NT + j) * 16 + e) * 64] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * NT + j) * 16 + e) * 64];
+    }
     float* stg = reinterpret_cast<float*>(&smem[0]) + wave * (32 * SP);
     const int sr = lane / C4;          // row within an RPI group
     const int sc = (lane % C4) * 4;    // column within the wave's slab

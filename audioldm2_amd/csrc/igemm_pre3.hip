@@ -2,15 +2,18 @@
 #include "igemm_kernel.h"
 
 namespace aldm {
-int igemm_launch_pre3(int BM, int BN, dim3 grid, hipStream_t st, const IgemmK& p) {
+int igemm_launch_pre3(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p) {
     constexpr int PRE = 3;
-#define ALDM_IG(BM_, BN_, WM_, WN_) \
-    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE>), grid, dim3(256), 0, st, p)
-    if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2);
-    else if (BM == 128 && BN == 64) ALDM_IG(128, 64, 2, 2);
-    else if (BM == 128 && BN == 32) ALDM_IG(128, 32, 4, 1);
-    else if (BM == 64 && BN == 128) ALDM_IG(64, 128, 2, 2);
-    else if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2);
+#define ALDM_IG(BM_, BN_, WM_, WN_, KG_) \
+    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE, KG_>), grid, dim3(256 * KG_), 0, st, p)
+    if (kgroups == 2) {
+        if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2, 2);
+        else return -1;
+    } else if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2, 1);
+    else if (BM == 128 && BN == 64) ALDM_IG(128, 64, 2, 2, 1);
+    else if (BM == 128 && BN == 32) ALDM_IG(128, 32, 4, 1, 1);
+    else if (BM == 64 && BN == 128) ALDM_IG(64, 128, 2, 2, 1);
+    else if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2, 1);
     else return -1;
 #undef ALDM_IG
     return 0;

@@ -80,14 +80,32 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift) {
     const int b = blockIdx.x;
     __shared__ float s_mean[64], s_rstd[64];
+    __shared__ double s_part[256][2];
     const int Cg = C / G;
+    // 256 threads: LPG lanes per group walk that group's chunk partials in a strided, fixed pattern
+    // (independent loads in flight instead of one thread chasing `chunks` dependent loads), then a
+    // fixed-order LDS combine -> deterministic.
+    const int LPG = 256 / G >= 1 ? 256 / G : 1;  // G <= 64 -> LPG >= 4
+    {
+        const int g = threadIdx.x / LPG, l = threadIdx.x % LPG;
+        double s = 0.0, ss = 0.0;
+        if (g < G) {
+            for (int ch = l; ch < chunks; ch += LPG) {
+                const float* w = ws + ((int64_t)(b * chunks + ch) * G + g) * 2;
+                s += (double)w[0];
+                ss += (double)w[1];
+            }
+        }
+        s_part[threadIdx.x][0] = s;
+        s_part[threadIdx.x][1] = ss;
+    }
+    __syncthreads();
     if (threadIdx.x < G) {
         const int g = threadIdx.x;
         double s = 0.0, ss = 0.0;
-        for (int ch = 0; ch < chunks; ++ch) {
-            const float* w = ws + ((int64_t)(b * chunks + ch) * G + g) * 2;
-            s += (double)w[0];
-            ss += (double)w[1];
+        for (int l = 0; l < LPG; ++l) {
+            s += s_part[g * LPG + l][0];
+            ss += s_part[g * LPG + l][1];
         }
         const double n = (double)P * Cg;
         const double mean = s / n;
@@ -107,52 +125,70 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
-// ---- LayerNorm: one wave64 per row, row kept in registers (C <= 2048), exact two-pass ---------
+// ---- LayerNorm: one wave64 per R rows, rows kept in registers (C <= 2048), exact two-pass --------
+// All R rows' 16-byte loads are issued before the first reduction: a wave that loads one 1 KiB row and
+// then runs two dependent shuffle trees is latency bound (1.9 TB/s measured); R independent rows in
+// flight per wave hide that latency.
 constexpr int LN_MAXV = 8;
 
+template <int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         float* __restrict__ y, int M, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= M) return;
     const int C4 = C >> 2;
-    const float* xr = x + (int64_t)row * C;
-    f32x4 v[LN_MAXV];
-    float s = 0.f;
+    f32x4 v[R][MAXV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 < C4) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    for (int r = 0; r < R; ++r) {
+        const float* xr = x + (int64_t)min(row0 + r, M - 1) * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            v[r][i] = c4 < C4 ? *reinterpret_cast<const f32x4*>(xr + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    f32x4 ga[MAXV], be[MAXV];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)C;
-    float q = 0.f;
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = min(lane + 64 * i, C4 - 1);
+        ga[i] = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+        be[i] = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+    }
+    float mean[R], rstd[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 < C4) {
-            const f32x4 dlt = v[i] - mean;
-            q += (dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]);
-        }
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        mean[r] = s / (float)C;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    float* yr = y + (int64_t)row * C;
+    for (int r = 0; r < R; ++r) {
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 < C4) {
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
-            const f32x4 o = (v[i] - mean) * rstd * ga + be;
-            *reinterpret_cast<f32x4*>(yr + 4 * c4) = o;
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + 64 * i < C4) {
+                const f32x4 dlt = v[r][i] - mean[r];
+                q += (dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        rstd[r] = 1.0f / sqrtf(q / (float)C + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= M) break;
+        float* yr = y + (int64_t)(row0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < C4) *reinterpret_cast<f32x4*>(yr + 4 * c4) = (v[r][i] - mean[r]) * rstd[r] * ga[i] + be[i];
         }
     }
 }
@@ -237,8 +273,16 @@ extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const floa
     ALDM_CHECK(x && y && gamma && beta, "aldm_layernorm: null pointer");
     ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "aldm_layernorm: C=%d must be a multiple of 4 and <= %d",
                C, 256 * LN_MAXV);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, y, M,
-                       C, gamma, beta, eps);
+    hipStream_t st = (hipStream_t)stream;
+#define ALDM_LN(V_, R_)                                                                                  \
+    hipLaunchKernelGGL((layernorm_kernel<V_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, C, \
+                       gamma, beta, eps)
+    const int nv = cdiv(C / 4, 64);
+    if (nv <= 1) ALDM_LN(1, 4);
+    else if (nv <= 2) ALDM_LN(2, 4);
+    else if (nv <= 4) ALDM_LN(4, 2);
+    else ALDM_LN(8, 1);
+#undef ALDM_LN
     ALDM_LAUNCH_CHECK("aldm_layernorm");
     return 0;
 }

@@ -55,10 +55,23 @@ class GraphStepper:
     def __call__(self):
         if self.use_graph and self.calls >= 1:
             if self.graph is None:
-                self.graph = torch.cuda.CUDAGraph()
+                g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(self.graph):
+                try:
+                    # thread_local: other threads (e.g. the RCCL watchdog of a multi-GPU run) may keep
+                    # calling HIP while this thread captures
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self.fn()
+                    self.graph = g
+                except RuntimeError as e:  # capture refused: keep sampling eagerly, say so once
+                    import sys
+                    print(f"[audioldm2_amd] HIP graph capture failed ({e}); continuing without a graph",
+                          file=sys.stderr, flush=True)
+                    self.use_graph = False
+                    torch.cuda.synchronize()
                     self.fn()
+                    self.calls += 1
+                    return
             self.graph.replay()
         else:
             self.fn()

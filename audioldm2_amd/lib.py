@@ -43,7 +43,7 @@ class IgemmDesc(C.Structure):
         ("stride_x", C.c_int64), ("stride_w", C.c_int64), ("stride_o", C.c_int64),
         ("rowbias_ld", C.c_int32), ("epi_mode", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("hint_bm", C.c_int32), ("hint_bn", C.c_int32), ("hint_splits", C.c_int32), ("reserved1", C.c_int32),
+        ("hint_bm", C.c_int32), ("hint_bn", C.c_int32), ("hint_splits", C.c_int32), ("hint_kgroups", C.c_int32),
     ]
 
 
@@ -52,9 +52,9 @@ _SIGS = {
     "aldm_last_error": (C.c_char_p, []),
     "aldm_igemm": (C.c_int, [C.POINTER(IgemmDesc), C.c_void_p]),
     "aldm_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                  C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "aldm_igemm_ws_floats": (C.c_int64, [C.POINTER(IgemmDesc)]),
-    "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int]),
+    "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_kn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

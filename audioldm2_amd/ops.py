@@ -58,13 +58,14 @@ PROFILE = None
 # the eager first DDIM step (every shape of the model is seen there), i.e. before graph capture.
 _ws = {}
 _ws_retired = []  # outgrown buffers stay alive: a captured HIP graph may still point at them
+WS_SLOT = 0  # concurrent branches (pipeline.apply_model_cfg on two streams) use distinct scratch slots
 
 
 def _workspace(lib, d: IgemmDesc, device) -> None:
     need = lib.aldm_igemm_ws_floats(C.byref(d))
     if need <= 0:
         return
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), WS_SLOT)
     buf = _ws.get(key)
     if buf is None or buf.numel() < need:
         if torch.cuda.is_current_stream_capturing():
@@ -100,7 +101,7 @@ def _tuned_table():
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "mi355x_igemm.json")
             if os.path.exists(path):
                 with open(path) as f:
-                    _TUNED = {k: v[:3] for k, v in json.load(f)["entries"].items()}
+                    _TUNED = {k: v[:4] for k, v in json.load(f)["entries"].items()}
     return _TUNED
 
 
@@ -111,20 +112,21 @@ def _igemm(d: IgemmDesc, what: str, device=None):
         TUNE_LOG.append(key)
     hint = _tuned_table().get(key)
     if hint is not None:
-        d.hint_bm, d.hint_bn, d.hint_splits = hint
+        d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = hint
     _workspace(lib, d, device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     if PROFILE is None:
         _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
         return
-    bm, bn, fl, sp = C.c_int(), C.c_int(), C.c_int64(), C.c_int()
-    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl), C.byref(sp)), what)
+    bm, bn, fl, sp, kg = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int()
+    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl), C.byref(sp), C.byref(kg)), what)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
     e1.record()
-    shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch, sp.value)
-    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape, _kernel_name(d, bm.value, bn.value)))
+    shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch,
+             sp.value * 10 + kg.value)
+    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape, _kernel_name(d, bm.value, bn.value, kg.value)))
 
 
 def _pre_mode(d: IgemmDesc) -> int:
@@ -140,16 +142,17 @@ def _pre_mode(d: IgemmDesc) -> int:
     return 4
 
 
-def _kernel_name(d: IgemmDesc, bm: int, bn: int) -> str:
+def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1) -> str:
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
-    (igemm_kernel<BM, BN, WM, WN, PRE>)."""
+    (igemm_kernel<BM, BN, WM, WN, PRE, KGRP>)."""
     wm, wn = (4, 1) if bn == 32 else (2, 2)
-    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {_pre_mode(d)}>"
+    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {_pre_mode(d)}, {kg}>"
 
 
-def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0) -> None:
-    """Tuning override for tools/tests: force tile / split-K of subsequent igemm launches (0 = auto)."""
-    _l.load().aldm_igemm_force(bm, bn, splits)
+def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0) -> None:
+    """Tuning override for tools/tests: force tile / split-K / wave groups of subsequent igemm launches
+    (bm = 0: automatic)."""
+    _l.load().aldm_igemm_force(bm, bn, splits, kgroups)
 
 
 def _npad(n: int) -> int:

@@ -318,7 +318,10 @@ class LatentDiffusion(nn.Module):
             ctxs.append(torch.cat([a, b], 0).contiguous())
             masks.append(torch.cat([ma, mb], 0).contiguous())
         y = None if yc is None else torch.cat([yu, yc], 0).float().contiguous()
-        return {"ctxs": ctxs, "masks": masks, "y": y}
+        f32 = lambda t: t.float().contiguous()
+        halves = [{"ctxs": [f32(c) for c in cs], "masks": [f32(m).reshape(c.shape[0], -1) for c, m in zip(cs, ms)],
+                   "y": None if yy is None else f32(yy)} for cs, ms, yy in ((cu, mu, yu), (cc, mc, yc))]
+        return {"ctxs": ctxs, "masks": masks, "y": y, "halves": halves}
 
     @torch.no_grad()
     def apply_model_cfg(self, x, t2, cond=None, uncond=None, prepared=None):
@@ -327,10 +330,38 @@ class LatentDiffusion(nn.Module):
         if prepared is None:
             prepared = self.prepare_cfg(cond, uncond)
         B = x.shape[0]
+        if os.environ.get("ALDM_CFG_STREAMS", "0") == "1" and x.shape[0] * 2 == t2.shape[0]:
+            return self._apply_model_cfg_two_streams(x, t2, prepared)
         x2 = x.repeat(2, 1, 1, 1) if x.shape[0] * 2 == t2.shape[0] else x
         eps = self.model.diffusion_model(x2.contiguous(), t2, context_list=prepared["ctxs"], y=prepared["y"],
                                          context_attn_mask_list=prepared["masks"])
         return eps.view(2, B, *eps.shape[1:])
+
+    def _apply_model_cfg_two_streams(self, x, t2, prepared):
+        """Opt-in (ALDM_CFG_STREAMS=1): the uncond and cond halves as two concurrent branches (two HIP
+        streams = parallel branches of the captured graph), each with its own context length.  Measured on
+        MI355X at B = 8: 36.9 -> 36.4 ms per step in one run, 35.3 -> 35.8 in another, i.e. within noise
+        of the single 2B pass, which therefore stays the default.  Results equal two sequential B passes."""
+        B = x.shape[0]
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_cfg_streams", None) is None:
+            self._cfg_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        eps = torch.empty((2, B) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        xc = x.contiguous()
+        for i, st in enumerate(self._cfg_streams):
+            st.wait_stream(cur)
+            h = prepared["halves"][i]
+            with torch.cuda.stream(st):
+                ops.WS_SLOT = i + 1
+                try:
+                    e = self.model.diffusion_model(xc, t2[i * B:(i + 1) * B], context_list=h["ctxs"], y=h["y"],
+                                                   context_attn_mask_list=h["masks"])
+                    eps[i].copy_(e)
+                finally:
+                    ops.WS_SLOT = 0
+        for st in self._cfg_streams:
+            cur.wait_stream(st)
+        return eps
 
     # -- sampling ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -156,19 +156,20 @@ class BasicTransformerBlock(nn.Module):
         self.heads = n_heads
         self.dim = dim
         self._pk = None
-        self._kv = None  # (context tensor, its _version, K|V projection) — see _context_kv
+        self._kv = None  # [(context tensor, its _version, K|V projection)], newest first — see _context_kv
 
     def _context_kv(self, context, pk):
         """K/V projection of the cross-attention context (attention.py:336-337).  The context is the
         same tensor for all 200 DDIM steps, so the projection is computed once and reused while the
         SAME tensor object (unmodified: same _version) is passed again.  The cache holds a reference to
         the context, so its storage cannot be recycled under us."""
-        c = self._kv
-        if c is not None and c[0] is context and c[1] == context._version:
-            return c[2]
+        for c in (self._kv or ()):
+            if c[0] is context and c[1] == context._version:
+                return c[2]
         kv = ops.linear(context, pk["kv2"])
         if not torch.cuda.is_current_stream_capturing():  # graph-pool memory must not outlive the graph
-            self._kv = (context, context._version, kv)
+            # two entries: the uncond and the cond context when CFG runs as two concurrent half passes
+            self._kv = [(context, context._version, kv)] + list(self._kv or ())[:1]
         return kv
 
     def _prepare(self):

@@ -117,7 +117,9 @@ typedef struct aldm_igemm_desc {
     /* ABI v3: tuned launch configuration for this shape (0 = pick with the built-in cost model):
        block tile hint_bm x hint_bn in {128x128,128x64,64x128,64x64,128x32} and split-K factor.
        audioldm2_amd/tuning/ (JSON) holds the table measured on MI355X (tools/igemm_autotune.py).  */
-    int32_t hint_bm, hint_bn, hint_splits, reserved1;
+    int32_t hint_bm, hint_bn, hint_splits;
+    int32_t hint_kgroups;  /* 2 = two 4-wave groups per block share the 64x64 tile's K loop (in-block
+                              split-K through LDS: no workspace, no reduce kernel); 0/1 = one group */
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -128,11 +130,11 @@ int aldm_igemm(const aldm_igemm_desc* d, void* stream);
 int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* d);
 /* Host-only query (no launch): the block tile / split-K factor aldm_igemm would pick for this
  * descriptor and the algorithmic FLOPs of the call (2*M*N*K*batch) — used by bench.py's roofline
- * accounting.  splits may be NULL.                                                              */
-int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits);
+ * accounting.  splits / kgroups may be NULL.                                                              */
+int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits, int* kgroups);
 /* Tuning override (tests / tools): force the block tile and split-K factor of subsequent
- * aldm_igemm calls on this thread; 0 = automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
-void aldm_igemm_force(int bm, int bn, int splits);
+ * aldm_igemm calls on this thread; bm = 0 => automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
+void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1

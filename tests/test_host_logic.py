@@ -142,7 +142,7 @@ def test_igemm_tuning_table_is_wellformed():
     for k, v in t["entries"].items():
         parts = k.split(",")
         assert len(parts) == len(t["fields"]) and all(p.lstrip("-").isdigit() for p in parts)
-        assert (v[0], v[1]) in tiles and 1 <= v[2] <= 16
+        assert (v[0], v[1]) in tiles and 1 <= v[2] <= 16 and v[3] in (1, 2)
     d = lib.IgemmDesc()
     d.B, d.H, d.W, d.C1, d.KH, d.KW, d.N = 1, 1, 77, 64, 1, 1, 32
     assert len(ops.tune_key(d).split(",")) == len(t["fields"])

@@ -99,6 +99,38 @@ def test_unet_full_vs_oracle_batch8_properties():
         assert rel(alone, out[sl]) < 1e-5  # same kernels; only tile/grid shapes differ
 
 
+def test_unet_full_batch16_vs_pytorch_rocm_eager():
+    """BASELINE config 2 size (8 prompts x CFG = 16 samples, 256x16 latent): the HIP UNet against the
+    oracle's functional restatement executed by stock PyTorch-ROCm ON THE SAME GPU (ATen / rocBLAS /
+    MIOpen, fp32) — every one of the 16 rows, tolerance 2e-4 max-norm relative — and both timed (the
+    PyTorch-ROCm eager number is the 'reference stack on this hardware' context for DESIGN.md)."""
+    from audioldm2_amd.unet import UNetModel
+    from oracle.unet import unet_forward
+    cfg = cases.UNET_FULL
+    m = load_det(UNetModel(**cfg))
+    sd = {k: v.detach().cuda() for k, v in m.state_dict().items()}
+    x, t, ctxs, masks, _ = cases.unet_inputs(cfg, 16, 256, 16, 32, seed=4)
+    xg, tg, cg, mg = x.cuda(), t.cuda(), cu(ctxs), cu(masks)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1) / n
+    with torch.no_grad():
+        ref, t_torch = timed(lambda: unet_forward(sd, cfg, xg, tg, cg, mg), 3)
+        out, t_hip = timed(lambda: m(xg, tg, context_list=cg, context_attn_mask_list=mg), 3)
+    e = rel(out, ref)
+    report(f"unet_full B=16 on MI355X: HIP path {t_hip:.1f} ms/pass (eager launches) vs PyTorch-ROCm eager fp32 "
+           f"{t_torch:.1f} ms/pass; max-norm rel err {e:.2e}")
+    assert e < MOD_TOL
+
+
 @pytest.mark.parametrize("name,dd,shapes", [("vae16k", cases.DDCONFIG_16K, [(2, 8, 32, 16), (1, 8, 256, 16)]),
                                             ("vae48k", cases.DDCONFIG_48K, [(1, 16, 16, 32)])])
 def test_vae_matches_reference_fixture(name, dd, shapes):
@@ -330,3 +362,34 @@ def test_pipeline_batch8_runs_and_is_batch_consistent(ld):
     s1, _ = DDIMSampler(ld).sample(4, 1, (8, 256, 16), cond1, eta=0.0, unconditional_guidance_scale=3.5,
                                    unconditional_conditioning=unc1, verbose=False, x_T=xT)
     assert rel(s1, s8[:1]) < 1e-4
+
+
+@pytest.mark.parametrize("model_name,wave_len", [("audioldm_48k", 491536),
+                                                   ("audioldm2-speech-gigaspeech", 163872),
+                                                   ("audioldm2-full-large-1150k", 163872)])
+def test_other_baseline_configs_run_end_to_end(model_name, wave_len):
+    """BASELINE configs 3-5 (48 kHz FiLM-conditioned model with the 4-level VAE and the 48 k vocoder;
+    speech model with 512 AudioMAE tokens; large model with transformer depth 2 and a context-free
+    third transformer): text_to_audio-shaped job with 2 DDIM steps, and one 2B CFG pass must equal two
+    B passes of the same HIP UNet."""
+    from audioldm2_amd.pipeline import build_model, make_batch_for_text_to_audio, seed_everything
+    torch.manual_seed(3)
+    m = build_model(model_name=model_name).cuda()
+    if torch.is_tensor(m.scale_factor):
+        m.scale_factor.fill_(0.75)
+    B = 2
+    batch = make_batch_for_text_to_audio("a test prompt", batchsize=B)
+    seed_everything(11)
+    m.latent_t_size = 128 if "48k" in model_name else 256
+    wav = m.generate_batch(batch, unconditional_guidance_scale=3.5, ddim_steps=2, n_gen=1, duration=10)
+    assert wav.shape == (B, 1, wave_len) and wav.dtype == np.float32 and np.isfinite(wav).all()
+    cond = m.get_learned_conditioning_dict(batch)
+    uncond = {k: m.cond_stage_models[v["model_idx"]].get_unconditional_condition(B)
+              for k, v in m.cond_stage_model_metadata.items()}
+    x = torch.randn(B, m.channels, m.latent_t_size, m.latent_f_size, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.tensor([301.0, 301.0]).cuda()
+    eps2 = m.apply_model_cfg(x, t.repeat(2), cond, uncond)
+    e_u, e_c = m.apply_model(x, t, uncond), m.apply_model(x, t, cond)
+    assert rel(eps2[0], e_u) < 1e-5 and rel(eps2[1], e_c) < 1e-5
+    del m
+    torch.cuda.empty_cache()

@@ -111,6 +111,36 @@ def test_igemm_every_tile_and_splitk(ops, bm, bn, splits):
     assert torch.equal(y1, y2), "split-K reduce must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("splits", [1, 3])
+@pytest.mark.parametrize("with_pre", [False, True])
+def test_igemm_two_wave_groups(ops, splits, with_pre):
+    """KGRP = 2: two 4-wave groups share one 64x64 tile's K loop (odd tile count: one group runs a
+    barrier-only iteration) and add their accumulators through LDS; alone and combined with split-K."""
+    B, C, N, H, W = 3, 136, 96, 13, 7  # K = 1224 -> 39 k-tiles
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    b = torch.randn(N, generator=g(3))
+    res = torch.randn(B, N, H, W, generator=g(5))
+    gamma, beta = torch.randn(C, generator=g(6)), torch.randn(C, generator=g(7))
+    a = cl(x)
+    kw = {}
+    xin = x
+    if with_pre:
+        sc, sh = ops.gn_stats(a, gamma.cuda(), beta.cuda(), groups=2, eps=1e-5)
+        kw = dict(pre=(sc, sh), pre_act=ops.ACT_SILU)
+        xin = F.silu(F.group_norm(x, 2, gamma, beta, eps=1e-5))
+    ref = F.conv2d(xin, w, b, padding=1) + res
+    pw = ops.pack_conv(w, b)
+    ops.igemm_force(64, 64, splits, 2)
+    try:
+        y1 = ops.conv(a, pw, pad=(1, 1), res=cl(res), **kw)
+        y2 = ops.conv(a, pw, pad=(1, 1), res=cl(res), **kw)
+    finally:
+        ops.igemm_force(0, 0, 0, 0)
+    assert rel_err(uncl(y1), ref) < GEMM_TOL
+    assert torch.equal(y1, y2)
+
+
 def test_igemm_auto_splitk_deep_level(ops):
     """The shape class that triggers automatic split-K (deepest UNet level: M = 1024, K = 5760) with
     the GroupNorm+SiLU prologue, against the same launch with split-K disabled."""

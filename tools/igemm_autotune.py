@@ -115,11 +115,11 @@ def tune(key, lib):
     nk = (K + 31) // 32
     flops = 2.0 * M * N * K * max(d.batch, 1)
     reps = 3 if flops > 2e10 else 8
-    d.hint_bm = d.hint_bn = d.hint_splits = 0
+    d.hint_bm = d.hint_bn = d.hint_splits = d.hint_kgroups = 0
     t_auto = time_launch(lib, d, reps)
-    bm0, bn0, fl, sp0 = C.c_int(), C.c_int(), C.c_int64(), C.c_int()
-    lib.aldm_igemm_plan(C.byref(d), C.byref(bm0), C.byref(bn0), C.byref(fl), C.byref(sp0))
-    best = (t_auto, bm0.value, bn0.value, sp0.value)
+    bm0, bn0, fl, sp0, kg0 = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int()
+    lib.aldm_igemm_plan(C.byref(d), C.byref(bm0), C.byref(bn0), C.byref(fl), C.byref(sp0), C.byref(kg0))
+    best = (t_auto, bm0.value, bn0.value, sp0.value, kg0.value)
     geglu = d.epi_mode == L.EPI_GEGLU
     tiles = [(128, 32)] if N <= 32 else TILES
     for bm, bn in tiles:
@@ -133,13 +133,16 @@ def tune(key, lib):
             blocks = math.ceil(M / bm) * math.ceil(N / bn) * max(d.batch, 1) * sp
             if sp > 1 and blocks > 3072:
                 continue
-            if (bm, bn, sp) == (bm0.value, bn0.value, sp0.value):
-                continue
-            d.hint_bm, d.hint_bn, d.hint_splits = bm, bn, sp
-            t = time_launch(lib, d, reps)
-            if t is not None and t < best[0]:
-                best = (t, bm, bn, sp)
-    return t_auto, best, (bm0.value, bn0.value, sp0.value), flops
+            for kg in ((1, 2) if (bm, bn) == (64, 64) else (1,)):
+                if kg == 2 and math.ceil(nk / sp) < 4:
+                    continue
+                if (bm, bn, sp, kg) == (bm0.value, bn0.value, sp0.value, kg0.value):
+                    continue
+                d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = bm, bn, sp, kg
+                t = time_launch(lib, d, reps)
+                if t is not None and t < best[0]:
+                    best = (t, bm, bn, sp, kg)
+    return t_auto, best, (bm0.value, bn0.value, sp0.value, kg0.value), flops
 
 
 def main():
@@ -158,9 +161,9 @@ def main():
         t_auto, best, auto_cfg, flops = tune(key, lib)
         total += t_auto * n
         if best[0] < 0.97 * t_auto:
-            entries[key] = [best[1], best[2], best[3], round(best[0], 1), round(t_auto, 1)]
+            entries[key] = [best[1], best[2], best[3], best[4], round(best[0], 1), round(t_auto, 1)]
             saved += (t_auto - best[0]) * n
-        report.append(f"{key} n={n} auto {auto_cfg} {t_auto:.1f}us -> best ({best[1]},{best[2]},{best[3]}) {best[0]:.1f}us"
+        report.append(f"{key} n={n} auto {auto_cfg} {t_auto:.1f}us -> best ({best[1]},{best[2]},{best[3]},{best[4]}) {best[0]:.1f}us"
                       f" {flops/best[0]/1e6:.1f} TF")
         print(report[-1], flush=True)
     print(f"# {len(entries)} of {len(counts)} geometries tuned; {saved/1e3:.2f} ms saved of {total/1e3:.2f} ms per 2-step job"
@@ -168,7 +171,7 @@ def main():
     with open(out, "w") as f:
         json.dump({"device": torch.cuda.get_device_name(0), "models": models,
                    "fields": list(ops._TUNE_FIELDS) + ["pre_mode"],
-                   "note": "value = [BM, BN, splits, tuned_us, cost_model_us]", "entries": entries}, f, indent=0)
+                   "note": "value = [BM, BN, splits, kgroups, tuned_us, cost_model_us]", "entries": entries}, f, indent=0)
 
 
 if __name__ == "__main__":

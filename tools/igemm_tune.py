@@ -30,7 +30,7 @@ def timeit(fn, iters=10, warm=2):
 
 
 def sweep(name, fn, flops, M, N, nk):
-    ops.igemm_force(0, 0, 0)
+    ops.igemm_force(0, 0, 0, 0)
     t_auto = timeit(fn)
     res = []
     for bm, bn in [(128, 128), (128, 64), (64, 128), (64, 64)]:
@@ -42,20 +42,21 @@ def sweep(name, fn, flops, M, N, nk):
             blocks = math.ceil(M / bm) * math.ceil(N / bn) * sp
             if sp > 1 and blocks > 2048:
                 continue
-            ops.igemm_force(bm, bn, sp)
-            try:
-                t = timeit(fn, iters=6, warm=1)
-            finally:
-                ops.igemm_force(0, 0, 0)
-            res.append((t, bm, bn, sp, blocks))
-    for t, bm, bn, sp, blocks in res:
-        print(f"CSV,{name},{M},{N},{nk},{bm},{bn},{sp},{t*1e6:.1f}")
-    print(f"CSV,{name},{M},{N},{nk},0,0,0,{t_auto*1e6:.1f}")
+            for kg in ((1, 2) if (bm, bn) == (64, 64) and nk // sp >= 4 else (1,)):
+                ops.igemm_force(bm, bn, sp, kg)
+                try:
+                    t = timeit(fn, iters=6, warm=1)
+                finally:
+                    ops.igemm_force(0, 0, 0, 0)
+                res.append((t, bm, bn, sp, blocks, kg))
+    for t, bm, bn, sp, blocks, kg in res:
+        print(f"CSV,{name},{M},{N},{nk},{bm},{bn},{sp},{kg},{t*1e6:.1f}")
+    print(f"CSV,{name},{M},{N},{nk},0,0,0,0,{t_auto*1e6:.1f}")
     res.sort()
     best = res[0]
-    line = "  ".join(f"{bm}x{bn}/s{sp}:{t*1e6:.0f}us" for t, bm, bn, sp, _ in res[:5])
+    line = "  ".join(f"{bm}x{bn}/s{sp}/g{kg}:{t*1e6:.0f}us" for t, bm, bn, sp, _, kg in res[:5])
     print(f"{name:34s} auto {t_auto*1e6:7.1f} us {flops/t_auto/1e12:6.1f} TF | best {best[0]*1e6:7.1f} us "
-          f"{flops/best[0]/1e12:6.1f} TF ({best[1]}x{best[2]} s{best[3]} blocks={best[4]}) | {line}", flush=True)
+          f"{flops/best[0]/1e12:6.1f} TF ({best[1]}x{best[2]} s{best[3]} g{best[5]} blocks={best[4]}) | {line}", flush=True)
 
 
 def main():
