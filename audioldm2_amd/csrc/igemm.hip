@@ -8,11 +8,11 @@
 namespace aldm {
 
 // per-prologue launchers (igemm_pre*.hip)
-int igemm_launch_pre0(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre1(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre2(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre3(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre4(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre0(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre1(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre2(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre3(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre4(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -324,12 +324,14 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_SILU) pre = PRE_AFFINE_SILU;
     else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) pre = PRE_LRELU;
     else pre = PRE_GENERIC;
+    // every block tile inside one sample -> scale/shift loaded once per k-tile (UNI kernels)
+    const bool uni = p.OHW % BM == 0;
     switch (pre) {
-        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, p.kgroups, grid, st, p); break;
-        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, p.kgroups, grid, st, p); break;
-        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, p.kgroups, grid, st, p); break;
-        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, p.kgroups, grid, st, p); break;
-        default: rc = igemm_launch_pre4(BM, BN, p.kgroups, grid, st, p); break;
+        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, p.kgroups, uni, grid, st, p); break;
+        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, p.kgroups, uni, grid, st, p); break;
+        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, p.kgroups, uni, grid, st, p); break;
+        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, p.kgroups, uni, grid, st, p); break;
+        default: rc = igemm_launch_pre4(BM, BN, p.kgroups, uni, grid, st, p); break;
     }
     if (rc) {
         set_error("aldm_igemm: no kernel for tile %dx%d", BM, BN);

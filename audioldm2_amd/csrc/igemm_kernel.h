@@ -76,7 +76,11 @@ constexpr int igemm_min_blocks(int BM, int BN) {
 // per CU this puts two waves on every SIMD, so one group's LDS/barrier/address turnaround (≈1700 cycles
 // per k-tile when alone, measured) hides behind the other group's MFMAs — an in-block split-K with no
 // workspace and no reduce kernel.
-template <int BM, int BN, int WM, int WN, int PRE, int KGRP>
+//
+// UNI (affine prologues only): every block tile lies inside ONE sample (OH*OW % BM == 0, checked by the
+// host), so the per-(sample, channel) GroupNorm scale/shift of a k-group is loaded once per k-tile
+// instead of once per row pass: 2 instead of 2*PA extra loads and 2 instead of 2*PA float4 registers.
+template <int BM, int BN, int WM, int WN, int PRE, int KGRP, bool UNI>
 __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN)) void igemm_kernel(const IgemmK p) {
     constexpr int MT = BM / (32 * WM);
     constexpr int NT = BN / (32 * WN);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
     constexpr bool AFF = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC;
     struct Stage {
         f32x4 ra[PA], rb[PB];
-        f32x4 rsc[AFF ? PA : 1], rsh[AFF ? PA : 1];
+        f32x4 rsc[(AFF && !UNI) ? PA : 1], rsh[(AFF && !UNI) ? PA : 1];
         unsigned avalid, bvalid;
     };
 
@@ -199,11 +203,18 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
             const int64_t off = ok ? (int64_t)pix * pitch + c : 0;
             r.ra[pp] = *reinterpret_cast<const f32x4*>(src + off);
             r.avalid |= (ok ? 1u : 0u) << pp;
-            if constexpr (AFF) {
+            if constexpr (AFF && !UNI) {
                 if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
                     const int64_t so = ok ? (int64_t)a_b[pp] * p.Cin + t_ci : 0;
                     r.rsc[pp] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
                     r.rsh[pp] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
+                }
+            }
+            if constexpr (AFF && UNI) {
+                if (pp == 0) {  // one sample per tile: same scale/shift row for every pass
+                    const int64_t so = kval ? (int64_t)(m0 / p.OHW) * p.Cin + t_ci : 0;
+                    r.rsc[0] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
+                    r.rsh[0] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
                 }
             }
         }
@@ -231,10 +242,11 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
     constexpr bool ELEMWISE = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_LRELU;
     auto xform_elem = [&](Stage& r, int pp, int c) {  // one component, in place
         float v = r.ra[pp][c];
+        constexpr int si = UNI ? 0 : 1;  // scale/shift register index = pp * si
         if constexpr (PRE == PRE_AFFINE) {
-            v = v * r.rsc[pp][c] + r.rsh[pp][c];
+            v = v * r.rsc[pp * si][c] + r.rsh[pp * si][c];
         } else if constexpr (PRE == PRE_AFFINE_SILU) {
-            v = silu_fast(v * r.rsc[pp][c] + r.rsh[pp][c]);
+            v = silu_fast(v * r.rsc[pp * si][c] + r.rsh[pp * si][c]);
         } else if constexpr (PRE == PRE_LRELU) {
             v = v > 0.0f ? v : v * d.pre_slope;
         }

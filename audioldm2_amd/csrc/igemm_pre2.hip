@@ -2,10 +2,16 @@
 #include "igemm_kernel.h"
 
 namespace aldm {
-int igemm_launch_pre2(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, const IgemmK& p) {
+int igemm_launch_pre2(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p) {
     constexpr int PRE = 2;
-#define ALDM_IG(BM_, BN_, WM_, WN_, KG_) \
-    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE, KG_>), grid, dim3(256 * KG_), 0, st, p)
+    constexpr bool HAS_UNI = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU;
+#define ALDM_IG1(BM_, BN_, WM_, WN_, KG_, U_) \
+    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE, KG_, U_>), grid, dim3(256 * KG_), 0, st, p)
+#define ALDM_IG(BM_, BN_, WM_, WN_, KG_)                            \
+    do {                                                            \
+        if (HAS_UNI && uni) ALDM_IG1(BM_, BN_, WM_, WN_, KG_, HAS_UNI); \
+        else ALDM_IG1(BM_, BN_, WM_, WN_, KG_, false);              \
+    } while (0)
     if (kgroups == 2) {
         if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2, 2);
         else return -1;
@@ -16,6 +22,7 @@ int igemm_launch_pre2(int BM, int BN, int kgroups, dim3 grid, hipStream_t st, co
     else if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2, 1);
     else return -1;
 #undef ALDM_IG
+#undef ALDM_IG1
     return 0;
 }
 }  // namespace aldm

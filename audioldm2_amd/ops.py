@@ -144,9 +144,11 @@ def _pre_mode(d: IgemmDesc) -> int:
 
 def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1) -> str:
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
-    (igemm_kernel<BM, BN, WM, WN, PRE, KGRP>)."""
+    (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI>)."""
     wm, wn = (4, 1) if bn == 32 else (2, 2)
-    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {_pre_mode(d)}, {kg}>"
+    pre = _pre_mode(d)
+    uni = "true" if pre in (1, 2) and (d.OH * d.OW) % bm == 0 else "false"
+    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {pre}, {kg}, {uni}>"
 
 
 def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0) -> None:
