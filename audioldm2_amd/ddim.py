@@ -87,6 +87,10 @@ class _NoiseFeed:
     def __init__(self, draw, steps, shape, with_mask, temperature, dev, chunk=8, mask_first=True):
         self.draw, self.steps, self.with_mask, self.temperature = draw, steps, with_mask, temperature
         self.mask_first = mask_first  # DDIM draws the q_sample noise before the step noise, DDPM after
+        # chunk boundaries: the first chunk is ONE step so the GPU starts right away, then `chunk` steps
+        self.bounds = [0, min(1, steps)]
+        while self.bounds[-1] < steps:
+            self.bounds.append(min(steps, self.bounds[-1] + chunk))
         self.chunk = chunk
         self.noise = torch.empty((steps,) + tuple(shape), device=dev, dtype=torch.float32)
         self.qnoise = torch.empty_like(self.noise) if with_mask else None
@@ -99,10 +103,9 @@ class _NoiseFeed:
 
     def produce_next(self):
         c = self.produced
-        lo = c * self.chunk
-        if lo >= self.steps:
+        if c + 1 >= len(self.bounds):
             return
-        hi = min(self.steps, lo + self.chunk)
+        lo, hi = self.bounds[c], self.bounds[c + 1]
         slot = c % len(self.pin)
         prev = self.events.get(c - len(self.pin))
         if prev is not None:
@@ -124,11 +127,15 @@ class _NoiseFeed:
         self.produced = c + 1
 
     def wait(self, i):
-        c = i // self.chunk
+        """Make the current stream wait for step i's noise; returns True when i opens a chunk (the caller
+        then draws the next chunk after launching this step)."""
+        c = 0 if i == 0 else 1 + (i - 1) // self.chunk
         while self.produced <= c:
             self.produce_next()
-        if i % self.chunk == 0:
+        first = i == self.bounds[c]
+        if first:
             torch.cuda.current_stream().wait_event(self.events[c])
+        return first
 
 
 class DDIMSampler(object):
@@ -253,38 +260,63 @@ class DDIMSampler(object):
             blend_coef = torch.stack([self.sqrt_alphas_cumprod[tr], self.sqrt_one_minus_alphas_cumprod[tr]],
                                      1).contiguous().to(dev)  # [S, 2] = {sqrt(abar_t), sqrt(1 - abar_t)}
 
-        # static buffers = the graph's inputs
-        x_cur = img.clone()
-        x_next = torch.empty_like(x_cur)
-        pred_x0 = torch.empty_like(x_cur)
-        t_cur = t_tab[0].clone()
-        coef_cur = coef[0].clone()
-        noise_cur = torch.empty_like(x_cur)
-
         cfg_fused = use_cfg and hasattr(self.model, "apply_model_cfg")
         prepared = self.model.prepare_cfg(cond, unconditional_conditioning) \
             if cfg_fused and hasattr(self.model, "prepare_cfg") else None
 
-        def step():
-            if use_cfg:
-                if cfg_fused:
-                    eps = self.model.apply_model_cfg(x_cur, t_cur, cond, unconditional_conditioning,
-                                                     prepared=prepared)
-                else:
-                    tl = t_cur[:b].long()
-                    e_u = self.model.apply_model(x_cur, tl, unconditional_conditioning)
-                    e_c = self.model.apply_model(x_cur, tl, cond)
-                    eps = torch.stack([e_u, e_c]).contiguous()
-            else:
-                eps = self.model.apply_model(x_cur, t_cur[:b].long(), cond).contiguous()
-            ops.ddim_step(x_cur, eps, noise_cur, coef_cur, x_next, pred_x0)
-            x_cur.copy_(x_next)
+        # The captured step graph, its static input buffers and the batched conditioning live on the UNet
+        # module and are reused by the next sampling run of the same geometry (text_to_audio in a loop):
+        # that run skips the eager first step and the re-capture (~0.1 s per job).  New conditioning is
+        # copied INTO the captured tensors and the cross-attention K/V projections are recomputed in
+        # place; invalidate_packed() (weights changed) drops the cache.
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        can_cache = (prepared is not None and mask is None and self.use_graph and hasattr(unet, "refresh_context_kv")
+                     and os.environ.get("ALDM_NO_GRAPH_CACHE", "0") != "1")
+        key = None
+        if can_cache:
+            key = (tuple(shape), tuple(tuple(c.shape) for c in prepared["ctxs"]),
+                   None if prepared["y"] is None else tuple(prepared["y"].shape))
+        ent = unet._graph_cache.get(key) if can_cache else None
+        if ent is not None:
+            for dst, src in zip(ent["prepared"]["ctxs"] + ent["prepared"]["masks"],
+                                prepared["ctxs"] + prepared["masks"]):
+                dst.copy_(src)
+            if prepared["y"] is not None:
+                ent["prepared"]["y"].copy_(prepared["y"])
+            unet.refresh_context_kv(ent["prepared"]["ctxs"])
+            ent["x_cur"].copy_(img)
+        else:
+            # static buffers = the graph's inputs
+            ent = {"x_cur": img.clone(), "x_next": torch.empty_like(img), "pred_x0": torch.empty_like(img),
+                   "t_cur": t_tab[0].clone(), "coef_cur": coef[0].clone(), "noise_cur": torch.empty_like(img),
+                   "prepared": prepared}
 
-        run_step = GraphStepper(step, self.use_graph)
+            def step(e=ent):
+                x_c = e["x_cur"]
+                if use_cfg:
+                    if cfg_fused:
+                        eps = self.model.apply_model_cfg(x_c, e["t_cur"], cond, unconditional_conditioning,
+                                                         prepared=e["prepared"])
+                    else:
+                        tl = e["t_cur"][:b].long()
+                        e_u = self.model.apply_model(x_c, tl, unconditional_conditioning)
+                        e_c = self.model.apply_model(x_c, tl, cond)
+                        eps = torch.stack([e_u, e_c]).contiguous()
+                else:
+                    eps = self.model.apply_model(x_c, e["t_cur"][:b].long(), cond).contiguous()
+                ops.ddim_step(x_c, eps, e["noise_cur"], e["coef_cur"], e["x_next"], e["pred_x0"])
+                x_c.copy_(e["x_next"])
+            ent["run_step"] = GraphStepper(step, self.use_graph)
+            if can_cache:
+                unet._graph_cache.clear()  # one geometry at a time: the graph pins its activation pool
+                unet._graph_cache[key] = ent
+        x_cur, pred_x0, t_cur, coef_cur, noise_cur = (ent["x_cur"], ent["pred_x0"], ent["t_cur"], ent["coef_cur"],
+                                                      ent["noise_cur"])
+        run_step = ent["run_step"]
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         for i, step_t in enumerate(time_range):
             index = total_steps - i - 1
-            feed.wait(i)  # current stream waits for the upload of step i's noise chunk
+            opens_chunk = feed.wait(i)  # current stream waits for the upload of step i's noise chunk
             t_cur.copy_(t_tab[i])
             coef_cur.copy_(coef[i])
             noise_cur.copy_(noise[i])
@@ -292,7 +324,7 @@ class DDIMSampler(object):
                 # img = q_sample(x0, ts)*mask + (1-mask)*img   (ddim.py:226-231, ddpm.py:430-436)
                 ops.inpaint_blend(x_cur, x0_d, qn[i], mask_d, blend_coef[i])
             run_step()  # eager the first time, then one HIP-graph replay per step
-            if i % feed.chunk == 0:
+            if opens_chunk:
                 feed.produce_next()  # draw + upload the NEXT chunk while the GPU works on this one
             if callback:
                 callback(i)

@@ -453,12 +453,12 @@ class LatentDiffusion(nn.Module):
         run_step = GraphStepper(step, os.environ.get("ALDM_NO_GRAPH", "0") != "1")
         intermediates = [x_cur.clone()]
         for n, i in enumerate(order):
-            feed.wait(n)
+            opens_chunk = feed.wait(n)
             t_cur.copy_(t_tab[n])
             coef_cur.copy_(coef[n])
             noise_cur.copy_(feed.noise[n])
             run_step()
-            if n % feed.chunk == 0:
+            if opens_chunk:
                 feed.produce_next()
             if mask is not None:
                 ops.inpaint_blend(x_cur, x0_d, feed.qnoise[n], mask_d, blend[n])

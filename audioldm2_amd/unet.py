@@ -381,17 +381,34 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(),
                                  nn.Conv2d(model_channels, out_channels, 3, padding=1))
         self._pk = None
+        self._graph_cache = {}  # captured DDIM step graph + its static buffers (ddim.DDIMSampler)
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     # -- packed-weight cache ---------------------------------------------------------------------
     def invalidate_packed(self):
-        """Drop every re-laid-out weight copy and cached context projection (call after mutating
-        parameters)."""
+        """Drop every re-laid-out weight copy, cached context projection and captured step graph (call
+        after mutating parameters)."""
+        self._graph_cache = {}
         for m in self.modules():
             if hasattr(m, "_pk"):
                 m._pk = None
             if hasattr(m, "_kv"):
                 m._kv = None
+
+    def refresh_context_kv(self, contexts):
+        """Recompute, IN PLACE, the cached cross-attention K/V projections of the given context tensors
+        (their contents were overwritten for a new sampling run; a captured step graph keeps reading
+        the same K/V buffers)."""
+        for m in self.modules():
+            if isinstance(m, BasicTransformerBlock) and m._kv:
+                pk = m._prepare()
+                new = []
+                for ctx, ver, kv in m._kv:
+                    if any(ctx is c for c in contexts):
+                        ops.linear(ctx, pk["kv2"], out=kv)
+                        ver = ctx._version
+                    new.append((ctx, ver, kv))
+                m._kv = new
 
     def _prepare(self):
         if self._pk is None:
