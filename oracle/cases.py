@@ -27,6 +27,12 @@ UNET_FILM_TINY = {"image_size": 64, "extra_film_condition_dim": 512, "context_di
                   "use_spatial_transformer": True, "transformer_depth": 1}
 
 
+UNET_48K = {"image_size": 64, "extra_film_condition_dim": 512, "context_dim": [None], "in_channels": 16,
+            "out_channels": 16, "model_channels": 128, "attention_resolutions": [8, 4, 2], "num_res_blocks": 2,
+            "channel_mult": [1, 2, 3, 5], "num_head_channels": 32, "use_spatial_transformer": True,
+            "transformer_depth": 1}  # utils.py:413-561 (audioldm_48k)
+
+
 def unet_inputs(cfg: dict, B: int, H: int, W: int, t5_len: int = 12, seed: int = 0):
     """x, t, context_list, mask_list, y for a UNet config."""
     g = torch.Generator().manual_seed(1234 + seed)
@@ -112,4 +118,12 @@ def e2e_masked_batch(B: int):
     fb = mel_input(B, 64, 1024, seed=11).permute(0, 2, 1).contiguous()
     b["log_mel_spec"] = fb
     b["fbank"] = fb
+    return b
+
+
+def e2e_batch_48k(B: int):
+    """e2e_batch with the 256-bin all-zero log-mel of the 48 kHz model (utils.py:443-447)."""
+    b = e2e_batch(B)
+    b["log_mel_spec"] = torch.zeros((B, 1024, 256))
+    b["fbank"] = b["log_mel_spec"]
     return b

@@ -194,6 +194,57 @@ def gen_e2e(steps: int, B: int, name: str):
     save(name, latent=rec["latent"], mel=rec["mel"], wave=wav, seconds=np.float32(dt), threads=np.int32(torch.get_num_threads()))
 
 
+def _ref_latent_diffusion_named(model_name: str, keys_json: str):
+    """Real reference LatentDiffusion for any config name, synthetic conditioners under the reference's
+    cond keys, deterministic hot-path weights."""
+    refimport.install()
+    import audioldm2.utils as ru
+    from audioldm2.latent_diffusion.models.ddpm import LatentDiffusion
+    from audioldm2_amd.pipeline import default_audioldm_config
+    P = ru.default_audioldm_config(model_name)["model"]["params"]
+    cond = default_audioldm_config(model_name)["model"]["params"]["cond_stage_config"]
+    for k in cond:
+        cond[k]["params"]["device"] = "cpu"
+    P["cond_stage_config"] = cond
+    P["device"] = "cpu"
+    torch.manual_seed(0)
+    ld = LatentDiffusion(**P).eval()
+    hot = {k: tuple(v.shape) for k, v in ld.state_dict().items()
+           if k.startswith("model.diffusion_model.") or k.startswith("first_stage_model.")}
+    new = weights.make_state_dict(hot, seed=0)
+    new["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    missing, unexpected = ld.load_state_dict(new, strict=False)
+    assert not unexpected
+    with open(os.path.join(OUT, keys_json), "w") as f:
+        json.dump({k: list(v) for k, v in hot.items()}, f)
+    return ld
+
+
+def gen_e2e_48k(steps: int, B: int, name: str):
+    """BASELINE config 3: reference generate_batch of audioldm_48k (FiLM-conditioned UNet on a [16,128,32]
+    latent, 4-level VAE, 48 kHz HiFi-GAN).  The 491 536-sample waveform is stored decimated (head + every
+    16th sample) to keep the fixture small."""
+    ld = _ref_latent_diffusion_named("audioldm_48k", "e2e48k_statedict_keys.json")
+    ld.latent_t_size = 128
+    rec = {}
+    orig_decode = ld.decode_first_stage
+
+    def decode_hook(z):
+        rec["latent"] = z.clone()
+        return orig_decode(z)
+    ld.decode_first_stage = decode_hook
+    _seed_all()
+    t0 = time.time()
+    batch = cases.e2e_batch(B)
+    batch["log_mel_spec"] = torch.zeros((B, 1024, 256))
+    batch["fbank"] = batch["log_mel_spec"]
+    wav = ld.generate_batch(batch, unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
+    print(f"{name}: reference generate_batch(48k) B={B} steps={steps}: {time.time()-t0:.1f}s wave {wav.shape} "
+          f"rms {np.sqrt((wav**2).mean()):.4f} latent std {rec['latent'].std():.3f}")
+    save(name, latent=rec["latent"], wave_head=wav[..., :32768], wave_dec=wav[..., ::16],
+         wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(np.sqrt((wav.astype(np.float64) ** 2).mean())))
+
+
 def _seed_all():
     import random
     random.seed(cases.E2E_SEED)
@@ -265,6 +316,8 @@ if __name__ == "__main__":
         gen_e2e(5, 2, "e2e_full_5step_b2")
     if "all" in what or "masked" in what:
         gen_e2e_masked(4, 1, "e2e_masked_4step_b1")
+    if "all" in what or "e2e48k" in what:
+        gen_e2e_48k(2, 1, "e2e_48k_2step_b1")
     if "all" in what or "ancestral" in what:
         gen_ancestral(4, 1, "ancestral_4step_b1")
     if "e2e200" in what:

@@ -26,14 +26,26 @@ _GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def hot_path_shapes(model_name: str = "audioldm2-full") -> Dict[str, tuple]:
     """Names/shapes of the reference's hot-path tensors (recorded from the real LatentDiffusion)."""
-    assert model_name == "audioldm2-full"
-    with open(os.path.join(_GOLD, "e2e_statedict_keys.json")) as f:
+    fname = {"audioldm2-full": "e2e_statedict_keys.json", "audioldm_48k": "e2e48k_statedict_keys.json"}[model_name]
+    with open(os.path.join(_GOLD, fname)) as f:
         return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def oracle_48k(seed: int = 0) -> "OracleLatentDiffusion":
+    """BASELINE config 3 (audioldm_48k): FiLM-conditioned UNet on a [16, 128, 32] latent, 4-level VAE,
+    48 kHz HiFi-GAN (utils.py:413-561)."""
+    from audioldm2_amd.pipeline import default_audioldm_config
+    o = OracleLatentDiffusion(sd=weights.make_state_dict(hot_path_shapes("audioldm_48k"), seed=seed),
+                              unet_cfg=cases.UNET_48K, ddconfig=cases.DDCONFIG_48K, hifigan_cfg=cases.HIFIGAN_48K,
+                              cond_cfg=default_audioldm_config("audioldm_48k")["model"]["params"]["cond_stage_config"])
+    o.channels, o.latent_t_size, o.latent_f_size = 16, 128, 32
+    return o
 
 
 class OracleLatentDiffusion:
     def __init__(self, sd: Optional[Dict[str, torch.Tensor]] = None, unet_cfg=None, ddconfig=None,
-                 hifigan_cfg=None, scale_factor: float = cases.SCALE_FACTOR, t5_len: int = 32, seed: int = 0):
+                 hifigan_cfg=None, scale_factor: float = cases.SCALE_FACTOR, t5_len: int = 32, seed: int = 0,
+                 cond_cfg=None):
         self.unet_cfg = unet_cfg or cases.UNET_FULL
         self.dd = ddconfig or cases.DDCONFIG_16K
         self.hcfg = hifigan_cfg or cases.HIFIGAN_16K
@@ -41,22 +53,35 @@ class OracleLatentDiffusion:
         self.scale_factor = scale_factor
         self.buffers = make_schedule_buffers(1000, 0.0015, 0.0195)
         from audioldm2_amd.pipeline import instantiate_from_config
-        cond_cfg = cases.e2e_cond_config("cpu", t5_len)
+        if cond_cfg is None:
+            cond_cfg = cases.e2e_cond_config("cpu", t5_len)
+        for v in cond_cfg.values():
+            v["params"]["device"] = "cpu"
         self.cond_keys = list(cond_cfg.keys())
         self.cond_models = {k: instantiate_from_config(v) for k, v in cond_cfg.items()}
         self.cond_stage_key = {k: v["cond_stage_key"] for k, v in cond_cfg.items()}
         self.channels, self.latent_t_size, self.latent_f_size = 8, 256, 16
 
     def apply_model(self, x, t, cond):
-        ctxs = [cond[k][0] for k in self.cond_keys]
-        masks = [cond[k][1] for k in self.cond_keys]
-        return unet_forward(self.sd, self.unet_cfg, x, t, ctxs, masks, prefix="model.diffusion_model.")
+        # DiffusionWrapper.forward (ddpm.py:1821-1879): film* keys -> y (squeeze(1), concatenated),
+        # crossattn* keys -> (context, mask) in config-key order
+        y, ctxs, masks = None, [], []
+        for k in self.cond_keys:
+            if "film" in k:
+                v = cond[k].squeeze(1)
+                y = v if y is None else torch.cat([y, v], dim=-1)
+            else:
+                ctxs.append(cond[k][0])
+                masks.append(cond[k][1])
+        return unet_forward(self.sd, self.unet_cfg, x, t, ctxs, masks, y=y, prefix="model.diffusion_model.")
 
     @torch.no_grad()
     def generate_batch(self, batch, unconditional_guidance_scale=3.5, ddim_steps=200, ddim_eta=1.0,
                        record: Optional[list] = None):
         B = batch["log_mel_spec"].shape[0]
-        torch.randn((B, 8, batch["log_mel_spec"].shape[1] // 4, batch["log_mel_spec"].shape[2] // 4))  # posterior draw
+        f = 2 ** (len(self.dd["ch_mult"]) - 1)
+        torch.randn((B, self.dd["z_channels"], batch["log_mel_spec"].shape[1] // f,
+                     batch["log_mel_spec"].shape[2] // f))  # posterior draw (distributions.py:37-41)
         cond = {k: m(batch if self.cond_stage_key[k] == "all" else batch[self.cond_stage_key[k]])
                 for k, m in self.cond_models.items()}
         uncond = None

@@ -422,3 +422,37 @@ def test_other_baseline_configs_run_end_to_end(model_name, wave_len):
     assert rel(eps2[0], e_u) < 1e-5 and rel(eps2[1], e_c) < 1e-5
     del m
     torch.cuda.empty_cache()
+
+
+def test_e2e_48k_matches_reference_generate_batch():
+    """BASELINE config 3 (audioldm_48k) end to end against the REAL reference's generate_batch fixture
+    (B=1, 2 DDIM steps, CFG 3.5, seed 42): FiLM-conditioned UNet, 4-level VAE decoder, 48 kHz HiFi-GAN."""
+    from audioldm2_amd.pipeline import build_model, seed_everything
+    g = gold("e2e_48k_2step_b1")
+    m = build_model(model_name="audioldm_48k")
+    with open(os.path.join(GOLD, "e2e48k_statedict_keys.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = weights.make_state_dict(shapes, seed=0)
+    sd["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    rec = {}
+    orig = m.decode_first_stage_cl
+
+    def hook(z):
+        rec["latent"] = z.clone()
+        return orig(z)
+    m.decode_first_stage_cl = hook
+    seed_everything(cases.E2E_SEED)
+    m.latent_t_size = 128
+    wave = m.generate_batch(cases.e2e_batch_48k(1), unconditional_guidance_scale=3.5, ddim_steps=2, n_gen=1, duration=10)
+    assert wave.shape == (1, 1, int(g["wave_len"]))
+    el = rms(rec["latent"].double().cpu().numpy() - g["latent"]) / rms(g["latent"])
+    eh = rms(wave[..., :32768].astype(np.float64) - g["wave_head"])
+    ed = rms(wave[..., ::16].astype(np.float64) - g["wave_dec"])
+    report(f"48k e2e 2 steps B=1: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} "
+           f"/ rms_ref {float(g['wave_rms']):.3e}")
+    assert el < 1e-4
+    assert max(eh, ed) < 1e-3 and max(eh, ed) / float(g["wave_rms"]) < 1e-3
+    del m
+    torch.cuda.empty_cache()

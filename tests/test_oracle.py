@@ -149,3 +149,17 @@ def test_ancestral_oracle_matches_reference_sample():
     z, first = o.sample_ancestral(cases.e2e_batch(1), 4)
     assert rel(first, g["first"]) < 1e-4
     assert rel(z, g["latent"]) < 1e-4
+
+
+def test_e2e_oracle_matches_reference_generate_batch_48k():
+    """BASELINE config 3 (audioldm_48k) vs the real reference's generate_batch fixture (B=1, 2 DDIM steps,
+    CFG 3.5): FiLM routing (y), 16-channel 128x32 latent, 4-level VAE decode, 48 kHz vocoder."""
+    from oracle.pipeline import oracle_48k
+    g = gold("e2e_48k_2step_b1")
+    o = oracle_48k()
+    torch.manual_seed(cases.E2E_SEED)
+    out = o.generate_batch(cases.e2e_batch_48k(1), unconditional_guidance_scale=3.5, ddim_steps=2)
+    assert out["wave"].shape[-1] == int(g["wave_len"])
+    assert rel(out["latent"], g["latent"]) < 1e-4
+    assert rel(out["wave"][..., :32768], g["wave_head"]) < 1e-4
+    assert rel(out["wave"][..., ::16], g["wave_dec"]) < 1e-4
