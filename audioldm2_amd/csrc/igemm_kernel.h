@@ -176,23 +176,28 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
     const int b_skg = packed ? tid / BN : akg, b_skgs = packed ? stepb : 0;
     const int b_sc = packed ? tid % BN : ar0, b_scs = packed ? 0 : 32;
 
-    // one in-flight k-tile of this thread's global loads
+    // ---- running gather state -----------------------------------------------------------------
+    // The address of a gathered float4 only moves by a constant (BK*KGRP channels) from one k-tile to
+    // the next while the tile stays inside one (tap, source tensor) segment; the full index arithmetic
+    // (bounds checks, upsample shift, 64-bit pixel*pitch products) is redone only when the segment
+    // changes.  Measured with s_memtime stamps: address generation was 800 (64x64) to 1500+ (128x128)
+    // cycles of every k-tile, as much as half the tile's MFMA time when a wave is alone on its SIMD.
     constexpr bool AFF = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU || PRE == PRE_GENERIC;
-    struct Stage {
-        f32x4 ra[PA], rb[PB];
-        f32x4 rsc[(AFF && !UNI) ? PA : 1], rsh[(AFF && !UNI) ? PA : 1];
-        unsigned avalid, bvalid;
-    };
-
-    auto issue_loads = [&](Stage& r, int kt) {
-        // ---- A: branch-free gather (invalid -> offset 0, masked at commit time) ----
+    constexpr int KSTEP = BK * KGRP;           // channels between two k-tiles of this wave group
+    const float* a_ptr[PA];                    // next tile's source of row pass pp (always a safe address)
+    const float* sc_ptr[(AFF && !UNI) ? PA : 1];
+    const float* sh_ptr[(AFF && !UNI) ? PA : 1];
+    unsigned a_okmask = 0;                     // bit pp: that source is real data (else zero padding)
+    int seg_hi = 0;                            // t_ci < seg_hi <=> still inside the current segment
+    auto recompute_gather = [&]() {
         const bool kval = t_kh < d.KH;  // k < K
         const bool first = t_ci < d.C1;
         const float* src = first ? x1 : x2;
         const int c = first ? t_ci : t_ci - d.C1;
         const int pitch = first ? pix1 : pix2;
         const int dh = t_kh * d.DH, dw = t_kw * d.DW;
-        r.avalid = 0;
+        seg_hi = kval ? (first ? d.C1 : p.Cin) : (1 << 30);  // past K: stay "inside" (always invalid)
+        a_okmask = 0;
 #pragma unroll
         for (int pp = 0; pp < PA; ++pp) {
             const int ihv = a_h[pp] + dh;
@@ -200,41 +205,86 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
             const bool ok = kval && (unsigned)ihv < (unsigned)p.HV && (unsigned)iwv < (unsigned)p.WV;
             const int ih = ihv >> p.shh, iw = iwv >> p.shw;
             const int pix = ok ? (a_pix[pp] + ih) * d.W + iw : 0;
-            const int64_t off = ok ? (int64_t)pix * pitch + c : 0;
-            r.ra[pp] = *reinterpret_cast<const f32x4*>(src + off);
-            r.avalid |= (ok ? 1u : 0u) << pp;
+            // invalid -> pixel 0 of the source at channel c (kval) or its base (k >= K): readable memory
+            a_ptr[pp] = src + (int64_t)pix * pitch + (kval ? c : 0);
+            a_okmask |= (ok ? 1u : 0u) << pp;
             if constexpr (AFF && !UNI) {
                 if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
-                    const int64_t so = ok ? (int64_t)a_b[pp] * p.Cin + t_ci : 0;
-                    r.rsc[pp] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
-                    r.rsh[pp] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
-                }
-            }
-            if constexpr (AFF && UNI) {
-                if (pp == 0) {  // one sample per tile: same scale/shift row for every pass
-                    const int64_t so = kval ? (int64_t)(m0 / p.OHW) * p.Cin + t_ci : 0;
-                    r.rsc[0] = *reinterpret_cast<const f32x4*>(d.pre_scale + so);
-                    r.rsh[0] = *reinterpret_cast<const f32x4*>(d.pre_shift + so);
+                    const int64_t so = (int64_t)a_b[pp] * p.Cin + (kval ? t_ci : 0);
+                    sc_ptr[pp] = d.pre_scale + so;
+                    sh_ptr[pp] = d.pre_shift + so;
                 }
             }
         }
-        // advance (kh, kw, ci) to this group's next k-tile
-        t_ci += BK * KGRP;
-        while (t_ci >= p.Cin) {
-            t_ci -= p.Cin;
-            if (++t_kw == d.KW) {
-                t_kw = 0;
-                ++t_kh;
+        if constexpr (AFF && UNI) {
+            const int64_t so = (int64_t)(m0 / p.OHW) * p.Cin + (kval ? t_ci : 0);
+            sc_ptr[0] = d.pre_scale + so;
+            sh_ptr[0] = d.pre_shift + so;
+        }
+    };
+    recompute_gather();
+    // B: running pointers too; validity is a compare against the running k index
+    const float* b_ptr[PB];
+    int b_kidx[PB];
+#pragma unroll
+    for (int pp = 0; pp < PB; ++pp) {
+        b_ptr[pp] = wgt + ((int64_t)(kt0 + grp) * b_kt + pp * b_pp + b_base);
+        b_kidx[pp] = (kt0 + grp) * b_ks + pp * b_kps + b_k0;
+    }
+
+    // one in-flight k-tile of this thread's global loads
+    struct Stage {
+        f32x4 ra[PA], rb[PB];
+        f32x4 rsc[(AFF && !UNI) ? PA : 1], rsh[(AFF && !UNI) ? PA : 1];
+        unsigned avalid, bvalid;
+    };
+
+    // loads the NEXT k-tile of this wave group (the gather state points at it), then advances the state
+    auto issue_loads = [&](Stage& r) {
+        r.avalid = a_okmask;
+#pragma unroll
+        for (int pp = 0; pp < PA; ++pp) r.ra[pp] = *reinterpret_cast<const f32x4*>(a_ptr[pp]);
+        if constexpr (AFF) {
+            if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
+#pragma unroll
+                for (int pp = 0; pp < ((AFF && !UNI) ? PA : 1); ++pp) {
+                    r.rsc[pp] = *reinterpret_cast<const f32x4*>(sc_ptr[pp]);
+                    r.rsh[pp] = *reinterpret_cast<const f32x4*>(sh_ptr[pp]);
+                }
             }
         }
-        // ---- B ----
         r.bvalid = 0;
 #pragma unroll
         for (int pp = 0; pp < PB; ++pp) {
-            const bool ok = kt * b_ks + pp * b_kps + b_k0 < b_klim && pp * b_nps + b_n0 < b_nlim;
-            const int64_t off = ok ? kt * b_kt + pp * b_pp + b_base : 0;
-            r.rb[pp] = *reinterpret_cast<const f32x4*>(wgt + off);
+            const bool ok = b_kidx[pp] < b_klim && pp * b_nps + b_n0 < b_nlim;
+            r.rb[pp] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[pp] : wgt);
             r.bvalid |= (ok ? 1u : 0u) << pp;
+            b_ptr[pp] += b_kt * KGRP;
+            b_kidx[pp] += b_ks * KGRP;
+        }
+        // advance A to this group's next k-tile
+        t_ci += KSTEP;
+        if (t_ci < seg_hi) {
+#pragma unroll
+            for (int pp = 0; pp < PA; ++pp) a_ptr[pp] += KSTEP;
+            if constexpr (AFF) {
+                if (PRE != PRE_GENERIC || d.pre_scale != nullptr) {
+#pragma unroll
+                    for (int pp = 0; pp < ((AFF && !UNI) ? PA : 1); ++pp) {
+                        sc_ptr[pp] += KSTEP;
+                        sh_ptr[pp] += KSTEP;
+                    }
+                }
+            }
+        } else {  // next tile starts in another tap / source tensor (or past K): full index arithmetic
+            while (t_ci >= p.Cin) {
+                t_ci -= p.Cin;
+                if (++t_kw == d.KW) {
+                    t_kw = 0;
+                    ++t_kh;
+                }
+            }
+            recompute_gather();
         }
     };
 
@@ -321,14 +371,14 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
         auto tile_of = [&](int it) { return kt0 + grp + it * KGRP; };
         Stage r0;
         if (tile_of(0) < kt1) {
-            issue_loads(r0, tile_of(0));
+            issue_loads(r0);
             commit(r0, 0);
         }
         __syncthreads();
         int buf = 0;
         for (int it = 0; it < n_it; ++it) {
             const bool cur = tile_of(it) < kt1, nxt = tile_of(it + 1) < kt1;
-            if (nxt) issue_loads(r0, tile_of(it + 1));
+            if (nxt) issue_loads(r0);
             if (cur) mma_half(buf, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use behind half the MFMAs
             if (nxt) commit(r0, buf ^ 1);

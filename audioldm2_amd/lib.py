@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaldm_hip.so")
+LIB_PATH = os.environ.get("ALDM_LIB_PATH") or os.path.join(_HERE, "libaldm_hip.so")  # override: debug builds
 ABI_VERSION = 3
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
