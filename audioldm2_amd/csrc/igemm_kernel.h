@@ -66,9 +66,10 @@ constexpr int igemm_min_blocks(int BM, int BN) {
     return BM * BN >= 128 * 128 ? 2 : ((BM * BN >= 64 * 128 || BN == 32) ? 3 : 4);
 }
 
-// Measured and rejected (profiles/r01_igemm_pipeline_variants_ab.txt): folding commit() into the
-// second half's MFMAs with sched_barrier fences, and a second register stage of global loads for the
-// 64x64 tile — both within +-2 % of this simpler pipeline on the UNet's shapes.
+// Measured and rejected (profiles/r01_igemm_pipeline_variants_ab.txt, r01_igemm_two_load_stages_ab.txt):
+// folding commit() into the second half's MFMAs with sched_barrier fences, and a second register stage
+// of global loads (first for the 64x64 tile, later for every tile) — all within +-2 % of this simpler
+// pipeline on the UNet's shapes: neither load latency nor prologue VALU is what limits it.
 //
 // KGRP = wave groups per block.  KGRP = 2 (512 threads): two 4-wave groups work on the SAME output tile,
 // each with its own LDS double buffer, group g taking k-tiles g, g+2, ...; their accumulators are added
