@@ -163,6 +163,8 @@ def main():
     from audioldm2_amd.pipeline import build_model, make_batch_for_text_to_audio, seed_everything
     rank, world, local = adist.init_distributed()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world > 1:  # one process per GPU on one host: do not oversubscribe the cores with intra-op threads
+        torch.set_num_threads(max(4, (os.cpu_count() or 8) // world))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
     dev = torch.device("cuda", torch.cuda.current_device())
 

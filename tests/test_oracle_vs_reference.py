@@ -1,0 +1,58 @@
+"""The oracle restatement against the LIVE reference classes (imported from /root/reference through
+oracle/refimport.py) on inputs that are NOT in the committed fixtures.  Runs only where the reference
+checkout exists (the build container); skipped on the GPU box.  CPU only."""
+import pytest
+import torch
+
+from oracle import cases, refimport, weights
+from oracle.unet import unet_forward
+from oracle.vae import hifigan_forward, vae_decode, vae_encode_moments
+
+pytestmark = pytest.mark.skipif(not refimport.available(), reason="reference checkout not present")
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _load_det(module, seed):
+    sd = weights.make_state_dict(weights.shapes_of(module), seed=seed)
+    module.load_state_dict(sd)
+    return sd
+
+
+@pytest.mark.parametrize("cfg,B,H,W,t5,seed", [(cases.UNET_TINY, 3, 24, 8, 5, 11), (cases.UNET_LARGE_TINY, 1, 16, 16, 20, 12),
+                                              (cases.UNET_FILM_TINY, 2, 16, 8, 0, 13)])
+def test_unet_oracle_equals_live_reference(cfg, B, H, W, t5, seed):
+    """openaimodel.UNetModel.forward (openaimodel.py:837-885) on fresh weights / shapes / seeds."""
+    ref = refimport.unet_cls()(**cfg).eval()
+    sd = _load_det(ref, seed)
+    x, t, ctxs, masks, y = cases.unet_inputs(cfg, B, H, W, max(t5, 1), seed=seed)
+    with torch.no_grad():
+        want = ref(x, t, y=y, context_list=ctxs, context_attn_mask_list=masks)
+        got = unet_forward(sd, cfg, x, t, ctxs, masks, y=y)
+    assert rel(got, want) < 1e-5
+
+
+def test_vae_oracle_equals_live_reference():
+    """AutoencoderKL.decode / .encode (autoencoder.py:103-117) for the 16 kHz ddconfig."""
+    refimport.install()
+    from audioldm2.latent_encoder.autoencoder import AutoencoderKL
+    dd = cases.DDCONFIG_16K
+    ae = AutoencoderKL(ddconfig=dd, embed_dim=dd["z_channels"], image_key="fbank").eval()
+    sd = _load_det(ae, 21)
+    z = cases.latent_input(1, 8, 24, 16, seed=21)
+    x = cases.mel_input(1, 64, 64, seed=22).permute(0, 2, 1)[:, None]
+    with torch.no_grad():
+        assert rel(vae_decode(sd, dd, z), ae.decode(z)) < 1e-5
+        assert rel(vae_encode_moments(sd, dd, x), ae.encode(x).parameters) < 1e-5
+
+
+def test_hifigan_oracle_equals_live_reference():
+    """hifigan.Generator.forward (hifigan/models.py:149-165), 16 kHz config."""
+    g = refimport.hifigan_generator(dict(cases.HIFIGAN_16K))
+    sd = _load_det(g, 31)
+    mel = cases.mel_input(2, 64, 20, seed=31)
+    with torch.no_grad():
+        assert rel(hifigan_forward(sd, cases.HIFIGAN_16K, mel), g(mel)) < 1e-5
