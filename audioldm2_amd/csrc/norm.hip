@@ -15,10 +15,16 @@ namespace aldm {
 //         scale[b,c] = rstd*gamma[c], shift[b,c] = beta[c] - mean*rstd*gamma[c].
 constexpr int GN_ITERS = 16;
 
+// FUSED: one block covers a whole (small) sample, keeps the group sums in LDS and finalises in the
+// same launch — for the deep UNet levels (P <= 256 pixels) the two-launch form is pure latency.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x1,
                                                          const float* __restrict__ x2, int P,
                                                          int C1, int C2, int G, int cols, int rows,
-                                                         int chunk_px, float* __restrict__ ws) {
+                                                         int chunk_px, float* __restrict__ ws, float eps,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
     const int C = C1 + C2;
     const int C4 = C >> 2;
     const int Cg4 = (C / G) >> 2;
@@ -31,7 +37,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     __shared__ float ps[256][2];
     // columns handled in passes of `cols` (cols = min(C4, 256))
     const int npass = (C4 + cols - 1) / cols;
-    for (int g = tid; g < 2 * G; g += 256) ws[((int64_t)(b * gridDim.x + chunk) * G) * 2 + g] = 0.f;
+    __shared__ float gsum[64][2];
+    if (FUSED) {
+        if (tid < 64) gsum[tid][0] = gsum[tid][1] = 0.f;
+    } else {
+        for (int g = tid; g < 2 * G; g += 256) ws[((int64_t)(b * gridDim.x + chunk) * G) * 2 + g] = 0.f;
+    }
     __syncthreads();
     for (int cp = 0; cp < npass; ++cp) {
         const int c4 = cp * cols + tx;
@@ -63,12 +74,35 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                         a += ps[t][0];
                         a2 += ps[t][1];
                     }
-                float* w = ws + ((int64_t)(b * gridDim.x + chunk) * G + g) * 2;
-                w[0] += a;
-                w[1] += a2;
+                if (FUSED) {
+                    gsum[g][0] += a;
+                    gsum[g][1] += a2;
+                } else {
+                    float* w = ws + ((int64_t)(b * gridDim.x + chunk) * G + g) * 2;
+                    w[0] += a;
+                    w[1] += a2;
+                }
             }
         }
         __syncthreads();
+    }
+    if (FUSED) {
+        const int Cg = C / G;
+        if (tid < G) {
+            const double n = (double)P * Cg;
+            const double mean = (double)gsum[tid][0] / n;
+            double var = (double)gsum[tid][1] / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gsum[tid][0] = (float)mean;
+            gsum[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            const int g = c / Cg;
+            const float sc = gsum[g][1] * (gamma ? gamma[c] : 1.f);
+            scale[(int64_t)b * C + c] = sc;
+            shift[(int64_t)b * C + c] = (beta ? beta[c] : 0.f) - gsum[g][0] * sc;
+        }
     }
 }
 
@@ -260,10 +294,15 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
     int cols, rows, chunk_px, chunks;
     gn_geometry(P, C, &cols, &rows, &chunk_px, &chunks);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(256), 0, st, x1, x2, P, C1, C2, G,
-                       cols, rows, chunk_px, ws);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, ws, chunks, P, C, G, eps, gamma,
-                       beta, scale, shift);
+    if ((int64_t)P * C <= 200 * 1024) {  // small sample (deep UNet levels): one block, one launch
+        hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(1, B), dim3(256), 0, st, x1, x2, P, C1, C2, G, cols,
+                           rows, P, ws, eps, gamma, beta, scale, shift);
+    } else {
+        hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, B), dim3(256), 0, st, x1, x2, P, C1, C2, G,
+                           cols, rows, chunk_px, ws, eps, gamma, beta, scale, shift);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, ws, chunks, P, C, G, eps, gamma,
+                           beta, scale, shift);
+    }
     ALDM_LAUNCH_CHECK("aldm_groupnorm_stats");
     return 0;
 }
