@@ -456,3 +456,54 @@ def test_e2e_48k_matches_reference_generate_batch():
     assert max(eh, ed) < 1e-3 and max(eh, ed) / float(g["wave_rms"]) < 1e-3
     del m
     torch.cuda.empty_cache()
+
+
+def _shard_worker(rank, world, port, out_dir, gB, steps):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), ALDM_DIST_BACKEND="gloo")
+    from audioldm2_amd import dist as adist
+    from audioldm2_amd.pipeline import build_model, seed_everything
+    r, w, _ = adist.init_distributed()
+    torch.manual_seed(1000 + rank)  # different random init per rank: the broadcast must make them equal
+    m = build_model(model_name="audioldm2-full").cuda()
+    m.scale_factor.fill_(0.75 if rank == 0 else 0.5)
+    sent = adist.broadcast_module(m, src=0)
+    assert sent > 1e9 and float(m.scale_factor) == 0.75
+    seed_everything(cases.E2E_SEED)
+    m.latent_t_size = 256
+    wav = m.generate_batch(cases.e2e_batch(gB), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1,
+                           duration=10, shard=(rank, world))
+    np.save(os.path.join(out_dir, f"wave{rank}.npy"), wav)
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in m.state_dict().items()}, os.path.join(out_dir, "sd.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_sharded_run_equals_single_process(tmp_path):
+    """SURVEY §8e on real kernels: two ranks (sharing this one GPU, gloo instead of RCCL) broadcast the
+    weights, draw the GLOBAL noise and sample contiguous halves of a 4-prompt batch; concatenated, the
+    result must equal the single-process run of the same batch (prompts are independent, RNG contract R)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from audioldm2_amd.pipeline import build_model, seed_everything
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    gB, steps = 4, 4  # the reference (and so this port) needs 1000 % steps == 0
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path), gB, steps), nprocs=2, join=True)
+    sharded = np.concatenate([np.load(os.path.join(tmp_path, f"wave{r}.npy")) for r in range(2)], axis=0)
+    m = build_model(model_name="audioldm2-full")
+    m.load_state_dict(torch.load(os.path.join(tmp_path, "sd.pt")), strict=False)
+    m = m.cuda()
+    seed_everything(cases.E2E_SEED)
+    m.latent_t_size = 256
+    single = m.generate_batch(cases.e2e_batch(gB), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1,
+                              duration=10)
+    assert sharded.shape == single.shape == (gB, 1, 163872)
+    e = rms(sharded.astype(np.float64) - single) / rms(single)
+    report(f"2-rank sharded vs single process, B={gB}, {steps} steps: wave rel rms {e:.2e}")
+    assert e < 1e-5  # same kernels; only tile/grid choices differ with the per-rank batch
