@@ -56,3 +56,20 @@ def test_hifigan_oracle_equals_live_reference():
     mel = cases.mel_input(2, 64, 20, seed=31)
     with torch.no_grad():
         assert rel(hifigan_forward(sd, cases.HIFIGAN_16K, mel), g(mel)) < 1e-5
+
+
+def test_audio_front_end_helpers_equal_live_reference():
+    """pad_wav / normalize_wav / _pad_spec of the inpainting front-end (utilities/audio/tools.py:9-25,71-84)
+    — host helpers of audioldm2_amd.pipeline — against the reference's own functions."""
+    import numpy as np
+    refimport.install()
+    import audioldm2.utilities.audio.tools as rt
+    from audioldm2_amd import pipeline as P
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal(5000).astype(np.float32) * 0.3 + 0.1
+    assert np.array_equal(P.normalize_wav(w), rt.normalize_wav(w))
+    for seg in (None, 5000, 8000):
+        assert np.array_equal(P.pad_wav(w[None], seg), rt.pad_wav(w[None], seg))
+    fb = torch.randn(1000, 65)
+    for tl in (1024, 900):
+        assert torch.equal(P._pad_spec(fb, tl), rt._pad_spec(fb, tl))
