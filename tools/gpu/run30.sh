@@ -1,0 +1,4 @@
+set -x
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_suite_final.log 2>&1; echo "gpu suite rc=$?"; tail -4 gpurun_out/gpu_suite_final.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
