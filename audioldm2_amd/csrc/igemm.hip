@@ -8,11 +8,11 @@
 namespace aldm {
 
 // per-prologue launchers (igemm_pre*.hip)
-int igemm_launch_pre0(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre1(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre2(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre3(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
-int igemm_launch_pre4(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre0(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre1(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_pre4(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -122,6 +122,20 @@ extern "C" void aldm_igemm_force(int bm, int bn, int splits, int kgroups) {
     g_force_bn = bn;
     g_force_splits = splits;
     g_force_kgroups = kgroups;
+}
+
+static int default_wave8_mask() {
+    static const int m = [] {
+        const char* e = getenv("ALDM_IGEMM_W8");
+        return e ? atoi(e) : 1;
+    }();
+    return m;
+}
+static thread_local int g_wave8_mask = -1;
+
+extern "C" int aldm_igemm_wave8_mask(int mask) {
+    g_wave8_mask = mask;
+    return mask < 0 ? default_wave8_mask() : mask;
 }
 
 static bool tile_supported(int BM, int BN) {
@@ -326,12 +340,21 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     else pre = PRE_GENERIC;
     // every block tile inside one sample -> scale/shift loaded once per k-tile (UNI kernels)
     const bool uni = p.OHW % BM == 0;
+    // 8 waves (512 threads, 4 waves/SIMD at 2 blocks/CU) on a tile: measured 1-7 % faster than the 4-wave
+    // 128x128 tile for the GroupNorm(+SiLU) prologue convs (profiles/r01_w8_ab.txt), a wash or worse without a
+    // prologue.  ALDM_IGEMM_W8 = bit mask of the tiles that use it (1: 128x128, 2: 64x128, 4: 128x64; bit 3:
+    // also launches without a GroupNorm prologue, 128x128 only); default 1, aldm_igemm_wave8_mask overrides.
+    const int env_w8 = g_wave8_mask < 0 ? default_wave8_mask() : g_wave8_mask;
+    const bool gn_pre = pre == PRE_AFFINE || pre == PRE_AFFINE_SILU;
+    const int tile_bit = (BM == 128 && BN == 128) ? 1 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 0;
+    const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
+                    (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0));
     switch (pre) {
-        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, p.kgroups, uni, grid, st, p); break;
-        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, p.kgroups, uni, grid, st, p); break;
-        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, p.kgroups, uni, grid, st, p); break;
-        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, p.kgroups, uni, grid, st, p); break;
-        default: rc = igemm_launch_pre4(BM, BN, p.kgroups, uni, grid, st, p); break;
+        case PRE_NONE: rc = igemm_launch_pre0(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+        case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+        case PRE_AFFINE_SILU: rc = igemm_launch_pre2(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+        case PRE_LRELU: rc = igemm_launch_pre3(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+        default: rc = igemm_launch_pre4(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
     }
     if (rc) {
         set_error("aldm_igemm: no kernel for tile %dx%d", BM, BN);

@@ -5,8 +5,8 @@
 // Design (MI355X-first, not a port of any cuDNN/ATen algorithm):
 //  * activations are channels-last, so 4 consecutive k of one tap are one 16-byte load and a
 //    1x1 conv, a Linear and a conv tap are the same gather;
-//  * block tile BM x BN x 32, 4 wave64 (one per SIMD); each wave owns MT x NT MFMA 32x32 tiles
-//    (16 accumulator VGPRs each);
+//  * block tile BM x BN x 32, WM x WN wave64 (4 = one per SIMD; 8 on the 128x128 prologue convs); each
+//    wave owns MT x NT MFMA 32x32 tiles (16 accumulator VGPRs each);
 //  * LDS image is k-group major: As[kg][row] / Bs[kg][col] hold float4 = 4 consecutive k, so one
 //    conflict-free ds_read_b128 feeds 4 MFMAs.  The K index inside the 8-wide sub-step is
 //    permuted (lane half h takes k = 4h..4h+3) — legal because A and B use the same permutation;
@@ -82,22 +82,30 @@ constexpr int igemm_min_blocks(int BM, int BN) {
 // host), so the per-(sample, channel) GroupNorm scale/shift of a k-group is loaded once per k-tile
 // instead of once per row pass: 2 instead of 2*PA extra loads and 2 instead of 2*PA float4 registers.
 template <int BM, int BN, int WM, int WN, int PRE, int KGRP, bool UNI>
-__global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN)) void igemm_kernel(const IgemmK p) {
+__global__ __launch_bounds__(64 * WM * WN * KGRP, (KGRP == 2 || WM * WN == 8) ? 4 : igemm_min_blocks(BM, BN))
+void igemm_kernel(const IgemmK p) {
     constexpr int MT = BM / (32 * WM);
     constexpr int NT = BN / (32 * WN);
-    constexpr int PA = BM / 32;  // A-loader passes (32 rows x 8 k-groups per pass)
-    constexpr int PB = BN / 32;  // B-loader passes
-    static_assert(WM * WN == 4, "4 waves");
+    // WM x WN waves share the tile: 4 (one per SIMD) or 8 (two per SIMD from ONE block: the 128x128 tile's
+    // LDS allows only two blocks per CU, so 8-wave blocks are how four waves per SIMD get to overlap
+    // their staging / barrier phases with each other's MFMAs)
+    constexpr int GT = 64 * WM * WN;   // threads of one wave group
+    constexpr int RPP = GT / 8;        // rows (A) / columns (NT-mode B) gathered per loader pass
+    constexpr int PA = BM / RPP;       // A-loader passes (RPP rows x 8 k-groups per pass)
+    constexpr int PB = KG * BN / GT;   // B-loader passes
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    static_assert(WM * WN == 4 || KGRP == 1, "8-wave tiles have one wave group");
+    static_assert(BM % RPP == 0 && (KG * BN) % GT == 0 && BN % RPP == 0, "loader tiling");
     // one raw LDS buffer: A/B double buffers during the K loop, per-wave output staging afterwards
     constexpr int A_F4 = 2 * KG * (BM + 1);
     constexpr int B_F4 = 2 * KG * (BN + 1);
     __shared__ f32x4 smem[KGRP * (A_F4 + B_F4)];
-    const int grp = KGRP == 1 ? 0 : (int)(threadIdx.x >> 8);
+    const int grp = KGRP == 1 ? 0 : (int)(threadIdx.x / GT);
     f32x4 (*As)[KG][BM + 1] = reinterpret_cast<f32x4 (*)[KG][BM + 1]>(&smem[grp * (A_F4 + B_F4)]);
     f32x4 (*Bs)[KG][BN + 1] = reinterpret_cast<f32x4 (*)[KG][BN + 1]>(&smem[grp * (A_F4 + B_F4) + A_F4]);
 
     const aldm_igemm_desc& d = p.d;
-    const int tid = threadIdx.x & 255;  // position inside the 4-wave group
+    const int tid = KGRP == 1 ? (int)threadIdx.x : (int)(threadIdx.x % GT);  // position inside the wave group
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -124,13 +132,13 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_all, kt0 + p.kt_per_split);
 
-    // ---- A loader bookkeeping: this thread gathers rows ar0 + 32*pp, k-group akg ----
+    // ---- A loader bookkeeping: this thread gathers rows ar0 + RPP*pp (RPP = threads/8), k-group akg ----
     const int akg = tid & 7;
     const int ar0 = tid >> 3;
     int a_pix[PA], a_h[PA], a_w[PA], a_b[PA];
 #pragma unroll
     for (int pp = 0; pp < PA; ++pp) {
-        const int m = m0 + ar0 + 32 * pp;
+        const int m = m0 + ar0 + RPP * pp;
         if (m < p.M) {
             const int b = m / p.OHW;
             const int rem = m - b * p.OHW;
@@ -162,20 +170,20 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
     // load pp of k-tile kt reads offset kt*b_kt + pp*b_pp + b_base; it is valid iff
     //   kt*b_ks + pp*b_kps + b_k0 < b_klim  and  pp*b_nps + b_n0 < b_nlim ;
     // it is stored at Bs[buf][b_skg + pp*b_skgs][b_sc + pp*b_scs].
-    //   PACKED [Kg][Npad][4]: thread -> column tid % BN, k-groups tid / BN + (256/BN)*pp
-    //   NT     Bmat[N][ldb] : thread -> row tid / 8 + 32*pp, k-group tid % 8
-    constexpr int stepb = 256 / BN;
+    //   PACKED [Kg][Npad][4]: thread -> column tid % BN, k-groups tid / BN + (GT/BN)*pp
+    //   NT     Bmat[N][ldb] : thread -> row tid / 8 + RPP*pp, k-group tid % 8
+    constexpr int stepb = GT / BN;
     const bool packed = d.b_mode == ALDM_B_PACKED;
     const int64_t b_kt = packed ? (int64_t)KG * p.Npad * 4 : BK;
-    const int64_t b_pp = packed ? (int64_t)stepb * p.Npad * 4 : (int64_t)32 * d.ldb;
+    const int64_t b_pp = packed ? (int64_t)stepb * p.Npad * 4 : (int64_t)RPP * d.ldb;
     const int64_t b_base = packed ? ((int64_t)(tid / BN) * p.Npad + n0 + tid % BN) * 4
                                   : (int64_t)(n0 + ar0) * d.ldb + 4 * akg;
     const int b_ks = packed ? KG : BK, b_kps = packed ? stepb : 0;
     const int b_k0 = packed ? tid / BN : 4 * akg, b_klim = packed ? p.Kg : d.K;
-    const int b_nps = packed ? 0 : 32, b_n0 = packed ? n0 + tid % BN : n0 + ar0;
+    const int b_nps = packed ? 0 : RPP, b_n0 = packed ? n0 + tid % BN : n0 + ar0;
     const int b_nlim = packed ? p.Npad : d.N;
     const int b_skg = packed ? tid / BN : akg, b_skgs = packed ? stepb : 0;
-    const int b_sc = packed ? tid % BN : ar0, b_scs = packed ? 0 : 32;
+    const int b_sc = packed ? tid % BN : ar0, b_scs = packed ? 0 : RPP;
 
     // ---- running gather state -----------------------------------------------------------------
     // The address of a gathered float4 only moves by a constant (BK*KGRP channels) from one k-tile to
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
             }
         }
         if (!((r.avalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
-        As[buf][akg][ar0 + 32 * pp] = v;
+        As[buf][akg][ar0 + RPP * pp] = v;
     };
     auto store_b = [&](Stage& r, int buf, int pp) {
         f32x4 v = r.rb[pp];
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256 * KGRP, KGRP == 2 ? 4 : igemm_min_blocks(BM, BN
     constexpr int RPI = 64 / C4;      // rows covered by one wave-wide float4 read
     constexpr int IT = 32 / RPI;      // reads per 32-row slab
     constexpr int ITC = IT < 4 ? IT : 4;  // ... processed ITC at a time
-    static_assert(4 * 32 * SP * 4 <= (A_F4 + B_F4) * 16, "staging must fit the K-loop LDS");
+    static_assert(WM * WN * 32 * SP * 4 <= (A_F4 + B_F4) * 16, "staging must fit the K-loop LDS");
     __syncthreads();  // every wave is done reading As/Bs
     if constexpr (KGRP == 2) {
         // add the two groups' accumulators: group 1 parks its registers in LDS (lane-linear, conflict

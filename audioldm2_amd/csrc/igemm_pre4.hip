@@ -2,20 +2,25 @@
 #include "igemm_kernel.h"
 
 namespace aldm {
-int igemm_launch_pre4(int BM, int BN, int kgroups, bool uni, dim3 grid, hipStream_t st, const IgemmK& p) {
+int igemm_launch_pre4(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p) {
     constexpr int PRE = 4;
     constexpr bool HAS_UNI = PRE == PRE_AFFINE || PRE == PRE_AFFINE_SILU;
 #define ALDM_IG1(BM_, BN_, WM_, WN_, KG_, U_) \
-    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE, KG_, U_>), grid, dim3(256 * KG_), 0, st, p)
+    hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, PRE, KG_, U_>), grid, dim3(64 * WM_ * WN_ * KG_), 0, st, p)
 #define ALDM_IG(BM_, BN_, WM_, WN_, KG_)                            \
     do {                                                            \
         if (HAS_UNI && uni) ALDM_IG1(BM_, BN_, WM_, WN_, KG_, HAS_UNI); \
         else ALDM_IG1(BM_, BN_, WM_, WN_, KG_, false);              \
     } while (0)
+    if constexpr (HAS_UNI) {  // 8-wave variants of the 64x128 / 128x64 tiles exist for the GroupNorm prologues only
+        if (kgroups == 1 && w8 && BM == 64 && BN == 128) { ALDM_IG(64, 128, 2, 4, 1); return 0; }
+        if (kgroups == 1 && w8 && BM == 128 && BN == 64) { ALDM_IG(128, 64, 4, 2, 1); return 0; }
+    }
     if (kgroups == 2) {
         if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2, 2);
         else return -1;
-    } else if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2, 1);
+    } else if (BM == 128 && BN == 128 && w8) ALDM_IG(128, 128, 2, 4, 1);  // 8 waves on the tile
+    else if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2, 1);
     else if (BM == 128 && BN == 64) ALDM_IG(128, 64, 2, 2, 1);
     else if (BM == 128 && BN == 32) ALDM_IG(128, 32, 4, 1, 1);
     else if (BM == 64 && BN == 128) ALDM_IG(64, 128, 2, 2, 1);

@@ -55,6 +55,7 @@ _SIGS = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "aldm_igemm_ws_floats": (C.c_int64, [C.POINTER(IgemmDesc)]),
     "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aldm_igemm_wave8_mask": (C.c_int, [C.c_int]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_kn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -145,8 +145,13 @@ def _pre_mode(d: IgemmDesc) -> int:
 def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1) -> str:
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI>)."""
-    wm, wn = (4, 1) if bn == 32 else (2, 2)
     pre = _pre_mode(d)
+    wm, wn = (4, 1) if bn == 32 else (2, 2)
+    # 8 waves per tile: same rule as csrc/igemm.hip (ALDM_IGEMM_W8 tile mask, default 128x128 GroupNorm prologues)
+    w8 = _wave8_mask if _wave8_mask >= 0 else int(os.environ.get("ALDM_IGEMM_W8", "1"))
+    bit = {(128, 128): 1, (64, 128): 2, (128, 64): 4}.get((bm, bn), 0)
+    if kg == 1 and d.epi_mode != _l.EPI_GEGLU and (w8 & bit) and (pre in (1, 2) or (bit == 1 and (w8 & 8))):
+        wm, wn = (4, 2) if bit == 4 else (2, 4)
     uni = "true" if pre in (1, 2) and (d.OH * d.OW) % bm == 0 else "false"
     return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {pre}, {kg}, {uni}>"
 
@@ -155,6 +160,17 @@ def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0) -> 
     """Tuning override for tools/tests: force tile / split-K / wave groups of subsequent igemm launches
     (bm = 0: automatic)."""
     _l.load().aldm_igemm_force(bm, bn, splits, kgroups)
+
+
+_wave8_mask = -1
+
+
+def igemm_wave8(mask: int = -1) -> int:
+    """Tuning override for tools/tests: which block tiles run with 8 wavefronts per tile (bit mask, see
+    aldm_igemm_wave8_mask in include/aldm_hip.h); mask < 0 restores the default."""
+    global _wave8_mask
+    _wave8_mask = mask
+    return _l.load().aldm_igemm_wave8_mask(mask)
 
 
 def _npad(n: int) -> int:

@@ -135,6 +135,10 @@ int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, 
 /* Tuning override (tests / tools): force the block tile and split-K factor of subsequent
  * aldm_igemm calls on this thread; bm = 0 => automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
 void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
+/* Tuning override (tests / tools): bit mask of the block tiles that run with 8 instead of 4 wavefronts per
+ * tile on this thread (1: 128x128, 2: 64x128, 4: 128x64 — GroupNorm-prologue launches; 8: 128x128 launches
+ * without a prologue too).  mask < 0 restores the default (1, or $ALDM_IGEMM_W8).  Returns the mask in force. */
+int aldm_igemm_wave8_mask(int mask);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1

@@ -162,6 +162,39 @@ def test_igemm_auto_splitk_deep_level(ops):
     assert rel_err(y, y1) < 1e-5
 
 
+@pytest.mark.parametrize("bm,bn", [(128, 128), (64, 128), (128, 64)])
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_igemm_eight_wave_tiles(ops, bm, bn, uniform, splits):
+    """The 8-wavefront variants of the 128x128 / 64x128 / 128x64 tiles (GroupNorm+SiLU prologue; per-row and
+    per-tile-uniform scale/shift loads), alone and with split-K: same results as the 4-wave tile, bit for bit
+    (the K order per output element is the same), and within tolerance of the fp32 reference."""
+    B, C, N = 3, 136, 96
+    H, W = (32, 8) if uniform else (13, 7)  # 256 output positions per sample: every tile inside one sample
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    b = torch.randn(N, generator=g(3))
+    res = torch.randn(B, N, H, W, generator=g(5))
+    gamma, beta = torch.randn(C, generator=g(6)), torch.randn(C, generator=g(7))
+    a = cl(x)
+    sc, sh = ops.gn_stats(a, gamma.cuda(), beta.cuda(), groups=2, eps=1e-5)
+    ref = F.conv2d(F.silu(F.group_norm(x, 2, gamma, beta, eps=1e-5)), w, b, padding=1) + res
+    pw = ops.pack_conv(w, b)
+    ops.igemm_force(bm, bn, splits)
+    try:
+        assert ops.igemm_wave8(15) == 15
+        y8 = ops.conv(a, pw, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU, res=cl(res))
+        y8n = ops.conv(a, pw, pad=(1, 1), res=cl(res))  # bit 3: no prologue, 128x128 only
+        ops.igemm_wave8(0)
+        y4 = ops.conv(a, pw, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU, res=cl(res))
+        y4n = ops.conv(a, pw, pad=(1, 1), res=cl(res))
+    finally:
+        ops.igemm_wave8(-1)
+        ops.igemm_force(0, 0, 0)
+    assert rel_err(uncl(y8), ref) < GEMM_TOL
+    assert torch.equal(y8, y4) and torch.equal(y8n, y4n)
+
+
 @pytest.mark.parametrize("mode", ["affine", "lrelu", "silu_only", "affine_gelu"])
 def test_igemm_prologue_modes(ops, mode):
     """Each templated operand-prologue (GN apply, leaky_relu, and the generic runtime path)."""
