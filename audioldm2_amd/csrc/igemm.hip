@@ -13,6 +13,11 @@ int igemm_launch_pre1(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid,
 int igemm_launch_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_pre4(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+// bf16-split ("BF16x6") variants (igemm_bx_pre*.hip)
+int igemm_launch_bx_pre0(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_bx_pre1(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_bx_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_bx_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -105,6 +110,48 @@ __global__ void pack_kn_kernel(const float* __restrict__ src, float* __restrict_
     }
 }
 
+// packed fp32 [Kg][Npad][4] -> bf16-split image [Ko][3][Npad][8 bf16], Ko = 4*ceil(Kg/8) k-octets (zero
+// padded to whole k-tiles): part 0/1/2 = hi/mid/lo of the exact truncation split w = hi + mid + lo (each
+// part = the top 16 bits of an fp32), element j of a slot = k 8*ko + j.  Same split as the kernel's A side.
+__global__ void pack_split_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int Kg, int Npad,
+                                  int Ko) {
+    const int64_t total = (int64_t)Ko * Npad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Npad);
+        const int ko = (int)(i / Npad);
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kg = 2 * ko + h;
+            f32x4 f = {0.f, 0.f, 0.f, 0.f};
+            if (kg < Kg) f = *reinterpret_cast<const f32x4*>(src + ((int64_t)kg * Npad + n) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * h + c] = f[c];
+        }
+        unsigned part[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, v[j]);
+            const float r1 = v[j] - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
+            const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+            const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+            part[0][j] = u0 >> 16;
+            part[1][j] = u1 >> 16;
+            part[2][j] = __builtin_bit_cast(unsigned, r2) >> 16;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            uint4 o;
+            o.x = part[q][0] | (part[q][1] << 16);
+            o.y = part[q][2] | (part[q][3] << 16);
+            o.z = part[q][4] | (part[q][5] << 16);
+            o.w = part[q][6] | (part[q][7] << 16);
+            dst[((int64_t)ko * 3 + q) * Npad + n] = o;
+        }
+    }
+}
+
 static int log2_exact(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -138,7 +185,25 @@ extern "C" int aldm_igemm_wave8_mask(int mask) {
     return mask < 0 ? default_wave8_mask() : mask;
 }
 
-static bool tile_supported(int BM, int BN) {
+// matrix-core path override (tests / tools): 0 = automatic (bf16-split when the descriptor carries w_split),
+// 1 = fp32 MFMA always, 2 = bf16-split wherever an instantiation exists
+static thread_local int g_force_mma = 0;
+extern "C" int aldm_igemm_mma(int mode) {
+    const int prev = g_force_mma;
+    if (mode >= 0 && mode <= 2) g_force_mma = mode;
+    return prev;
+}
+
+static int pre_mode_of(const aldm_igemm_desc& d) {
+    if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) return PRE_NONE;
+    if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_NONE) return PRE_AFFINE;
+    if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_SILU) return PRE_AFFINE_SILU;
+    if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) return PRE_LRELU;
+    return PRE_GENERIC;
+}
+
+static bool tile_supported(int BM, int BN, bool bx) {
+    if (BM == 256 && BN == 128) return bx;  // 8-wave tile of the bf16-split kernels only
     return (BM == 128 && (BN == 128 || BN == 64 || BN == 32)) || (BM == 64 && (BN == 128 || BN == 64));
 }
 
@@ -213,20 +278,33 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     // profiles/r01_igemm_tune.txt): S = un-overlapped staging cycles per k-tile (per 32 A rows / B
     // columns; x1.5 with a GroupNorm/SiLU prologue), F = fixed block prologue + epilogue, reduce =
     // 10k cycles + (splits + 1) * M * N * 4 B at 2000 B/cycle.
-    auto occ_of = [](int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : ((bm * bn >= 64 * 128 || bn == 32) ? 3 : 4); };
+    // bf16-split path (BX): 6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 per 16 k (x0.375 matrix-pipe
+    // time), the LDS image is 1.5x larger (1 / 2 / 3 resident blocks for the three tile sizes) and staging
+    // pays the operand split.
+    const int pre = pre_mode_of(d);
+    const bool bx_ok = d.w_split != nullptr && d.b_mode == ALDM_B_PACKED && d.stride_w == 0 && d.batch == 1 &&
+                       pre != PRE_GENERIC && (reinterpret_cast<uintptr_t>(d.w_split) & 15) == 0 &&
+                       (g_force_mma == 2 || (g_force_mma == 0 && d.hint_mma != 1));
+    auto occ_of = [&](int bm, int bn) {
+        if (bx_ok && bn != 32) return bm * bn >= 128 * 128 ? 1 : (bm * bn >= 64 * 128 ? 2 : 3);  // 256x128: 1
+        return bm * bn >= 128 * 128 ? 2 : ((bm * bn >= 64 * 128 || bn == 32) ? 3 : 4);
+    };
     const double pre_w = (d.pre_scale != nullptr || d.pre_act != ALDM_ACT_NONE) ? 1.5 : 1.0;
     auto cost_of = [&](int bm, int bn, int sp, int kg, int* sp_eff) -> double {
+        const bool bx = bx_ok && bn != 32;
+        const double mf = bx ? 0.375 : 1.0;
         const int kt = cdiv(nk, sp);
         sp = cdiv(nk, kt);
         *sp_eff = sp;
         const double blocks = (double)cdiv64(Mz, bm) * cdiv(d.N, bn) * d.batch * sp;
-        const double L = (double)kt * bm * bn / 4.0;
-        const int o = kg == 2 ? 2 : occ_of(bm, bn);  // 512-thread blocks: two per CU
-        const double S = 300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32), F = 4000.0 + (kg == 2 ? 600.0 : 0.0);
+        const double L = (double)kt * bm * bn / 4.0 * mf;
+        const int o = kg == 2 ? (bx ? 1 : 2) : occ_of(bm, bn);  // 512-thread blocks: two per CU (one with BX)
+        const double S = (300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32)) * (bx ? 1.3 : 1.0);
+        const double F = 4000.0 + (kg == 2 ? 600.0 : 0.0);
         const int64_t nb = (int64_t)((blocks + 255.0) / 256.0);
         const int64_t full = nb / o, last = nb - full * o;
         // critical path of one wave group: it multiplies every kg-th k-tile
-        const double one = (double)cdiv(kt, kg) * ((double)bm * bn / 4.0 + S) + F;
+        const double one = (double)cdiv(kt, kg) * ((double)bm * bn / 4.0 * mf + S) + F;
         double T = full * std::max(one, o * L);
         if (last) T += std::max(one, last * L);
         if (sp > 1) T += 10000.0 + (double)(sp + 1) * Mz * d.N * d.batch * 4.0 / 2000.0;
@@ -242,7 +320,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     if (f_bm) {
         BM = f_bm;
         BN = f_bn;
-        ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm: unsupported forced/hinted tile %dx%d", BM, BN);
+        ALDM_CHECK(tile_supported(BM, BN, bx_ok), "aldm_igemm: unsupported forced/hinted tile %dx%d", BM, BN);
         ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: the GEGLU epilogue needs a 128-column tile");
         if (f_sp > 0 && can_split && nk / f_sp >= 1) splits = f_sp;
         if (f_kg == 2) {
@@ -253,12 +331,12 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         BM = 128;
         BN = 32;
     } else {
-        static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+        static const int cand[5][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}, {256, 128}};
         static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
         double best = 1e300;
         BM = 64;
         BN = 64;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < (bx_ok ? 5 : 4); ++c) {
             const int bm = cand[c][0], bn = cand[c][1];
             if (geglu ? bn != 128 : (bn > 64 && d.N <= 64)) continue;  // 
             for (int si = 0; si < 8; ++si) {
@@ -295,11 +373,13 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     }
     p.splits = splits;
     p.kgroups = kgroups;
+    p.bx = bx_ok && BN != 32 ? 1 : 0;
+    p.pre = pre;
     return 0;
 }
 
 extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int64_t* flops, int* splits,
-                               int* kgroups) {
+                               int* kgroups, int* mma) {
     IgemmK p;
     int BM, BN;
     const int rc = igemm_prepare(dd, p, BM, BN);
@@ -309,6 +389,7 @@ extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int6
     if (flops) *flops = 2ll * p.M * p.d.N * p.d.K * p.d.batch;
     if (splits) *splits = p.splits;
     if (kgroups) *kgroups = p.kgroups;
+    if (mma) *mma = p.bx ? ALDM_MMA_BF16X6 : ALDM_MMA_F32;
     return 0;
 }
 
@@ -332,12 +413,7 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     const aldm_igemm_desc& d = p.d;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.splits, (unsigned)d.batch);
     hipStream_t st = (hipStream_t)stream;
-    int pre;
-    if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_NONE;
-    else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_NONE) pre = PRE_AFFINE;
-    else if (d.pre_scale != nullptr && d.pre_act == ALDM_ACT_SILU) pre = PRE_AFFINE_SILU;
-    else if (d.pre_scale == nullptr && d.pre_act == ALDM_ACT_LRELU) pre = PRE_LRELU;
-    else pre = PRE_GENERIC;
+    const int pre = p.pre;
     // every block tile inside one sample -> scale/shift loaded once per k-tile (UNI kernels)
     const bool uni = p.OHW % BM == 0;
     // 8 waves (512 threads, 4 waves/SIMD at 2 blocks/CU) on a tile: measured 1-7 % faster than the 4-wave
@@ -347,8 +423,17 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     const int env_w8 = g_wave8_mask < 0 ? default_wave8_mask() : g_wave8_mask;
     const bool gn_pre = pre == PRE_AFFINE || pre == PRE_AFFINE_SILU;
     const int tile_bit = (BM == 128 && BN == 128) ? 1 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 0;
+    // BX: the 128x128 image leaves room for one block per CU, so that tile takes 8 waves for every prologue
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
-                    (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0));
+                    (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
+    if (p.bx) {
+        switch (pre) {
+            case PRE_NONE: rc = igemm_launch_bx_pre0(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+            case PRE_AFFINE: rc = igemm_launch_bx_pre1(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+            case PRE_AFFINE_SILU: rc = igemm_launch_bx_pre2(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+            default: rc = igemm_launch_bx_pre3(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
+        }
+    } else
     switch (pre) {
         case PRE_NONE: rc = igemm_launch_pre0(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
         case PRE_AFFINE: rc = igemm_launch_pre1(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
@@ -366,6 +451,28 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
                            dim3(256), 0, st, p);
     }
     ALDM_LAUNCH_CHECK("aldm_igemm");
+    return 0;
+}
+
+extern "C" int64_t aldm_split_bytes(int K, int N) {
+    if (K <= 0 || N <= 0) return 0;
+    const int Npad = (N + 31) / 32 * 32;
+    const int64_t Ko = 4ll * ((K + 31) / 32);  // k-octets, padded to whole 32-wide k-tiles
+    return Ko * 3 * Npad * 16;
+}
+
+extern "C" int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* stream) {
+    ALDM_CHECK(packed && dst && K > 0 && N > 0, "aldm_pack_split_bf16: bad args");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+               "aldm_pack_split_bf16: operands must be 16-byte aligned");
+    const int Npad = (N + 31) / 32 * 32;
+    const int Kg = (K + 3) / 4;
+    const int Ko = 4 * ((K + 31) / 32);
+    const int64_t total = (int64_t)Ko * Npad;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 65535);
+    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed,
+                       reinterpret_cast<uint4*>(dst), Kg, Npad, Ko);
+    ALDM_LAUNCH_CHECK("aldm_pack_split_bf16");
     return 0;
 }
 

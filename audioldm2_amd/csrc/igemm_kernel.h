@@ -25,6 +25,7 @@
 //  * blockIdx is remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace aldm {
 
@@ -34,11 +35,23 @@ struct IgemmK {
     int splits, kt_per_split;  // split-K: k-tiles [s*kt_per_split, ...) per blockIdx.y
     int kgroups;               // wave groups per block (1 or 2, see igemm_kernel)
     int rb_ld;                 // row-bias pitch
+    int bx;                    // 1: bf16-split kernels (d.w_split), 0: fp32 MFMA
+    int pre;                   // PRE_* prologue mode of the descriptor
 };
 
 enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4 };
 
+#ifndef ALDM_BX_INTERLEAVE
+#define ALDM_BX_INTERLEAVE 1
+#endif
+#ifndef ALDM_ABLATE
+#define ALDM_ABLATE 0  // debug builds only (tools/gpu/build_ablate.sh): drop pieces of the BX K loop to time the rest
+#endif
 constexpr int BK = 32;
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using u32x2 = unsigned __attribute__((ext_vector_type(2)));
+// the upper halves of two dwords as one dword (lo half from a): two truncated bf16 side by side
+__device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 constexpr int KG = BK / 4;
 
 // one output element through the fused epilogue (shared by the GEMM kernel and the split-K reduce)
@@ -66,6 +79,19 @@ constexpr int igemm_min_blocks(int BM, int BN) {
     return BM * BN >= 128 * 128 ? 2 : ((BM * BN >= 64 * 128 || BN == 32) ? 3 : 4);
 }
 
+// LDS bytes of one block (A/B double buffers; BX = bf16-split image, see igemm_kernel)
+constexpr int igemm_lds_bytes(int BM, int BN, int kgrp, bool BX) {
+    return BX ? kgrp * 2 * 12 * (BM + 2 + BN + 2) * 16 : kgrp * 2 * 8 * (BM + 1 + BN + 1) * 16;
+}
+// waves per SIMD the register budget must allow = what the LDS lets be resident (waves = WM*WN*KGRP)
+constexpr int igemm_waves_per_simd(int BM, int BN, int waves, bool BX) {
+    if (!BX) return waves == 8 ? 4 : igemm_min_blocks(BM, BN);
+    const int kgrp = (waves == 8 && BM == 64 && BN == 64) ? 2 : 1;
+    const int blocks = (160 * 1024) / igemm_lds_bytes(BM, BN, kgrp, true);
+    const int w = blocks * waves / 4;
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
 // Measured and rejected (profiles/r01_igemm_pipeline_variants_ab.txt, r01_igemm_two_load_stages_ab.txt):
 // folding commit() into the second half's MFMAs with sched_barrier fences, and a second register stage
 // of global loads (first for the 64x64 tile, later for every tile) — all within +-2 % of this simpler
@@ -81,8 +107,8 @@ constexpr int igemm_min_blocks(int BM, int BN) {
 // UNI (affine prologues only): every block tile lies inside ONE sample (OH*OW % BM == 0, checked by the
 // host), so the per-(sample, channel) GroupNorm scale/shift of a k-group is loaded once per k-tile
 // instead of once per row pass: 2 instead of 2*PA extra loads and 2 instead of 2*PA float4 registers.
-template <int BM, int BN, int WM, int WN, int PRE, int KGRP, bool UNI>
-__global__ __launch_bounds__(64 * WM * WN * KGRP, (KGRP == 2 || WM * WN == 8) ? 4 : igemm_min_blocks(BM, BN))
+template <int BM, int BN, int WM, int WN, int PRE, int KGRP, bool UNI, bool BX = false>
+__global__ __launch_bounds__(64 * WM * WN * KGRP, igemm_waves_per_simd(BM, BN, WM * WN * KGRP, BX))
 void igemm_kernel(const IgemmK p) {
     constexpr int MT = BM / (32 * WM);
     constexpr int NT = BN / (32 * WN);
@@ -92,17 +118,22 @@ void igemm_kernel(const IgemmK p) {
     constexpr int GT = 64 * WM * WN;   // threads of one wave group
     constexpr int RPP = GT / 8;        // rows (A) / columns (NT-mode B) gathered per loader pass
     constexpr int PA = BM / RPP;       // A-loader passes (RPP rows x 8 k-groups per pass)
-    constexpr int PB = KG * BN / GT;   // B-loader passes
+    constexpr int PB = (BX ? 12 : KG) * BN / GT;   // B-loader passes
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
     static_assert(WM * WN == 4 || KGRP == 1, "8-wave tiles have one wave group");
-    static_assert(BM % RPP == 0 && (KG * BN) % GT == 0 && BN % RPP == 0, "loader tiling");
-    // one raw LDS buffer: A/B double buffers during the K loop, per-wave output staging afterwards
-    constexpr int A_F4 = 2 * KG * (BM + 1);
-    constexpr int B_F4 = 2 * KG * (BN + 1);
+    static_assert(BM % RPP == 0 && ((BX ? 12 : KG) * BN) % GT == 0 && BN % RPP == 0, "loader tiling");
+    // one raw LDS buffer: A/B double buffers during the K loop, per-wave output staging afterwards.
+    // fp32 image: LG = 8 k-groups (float4 = 4 consecutive k) per row and k-tile.  BX image: LG = 12 16-byte
+    // slots per row / column and k-tile = 4 k-octets x 3 bf16 parts (8 bf16 = 8 consecutive k per slot);
+    // A is indexed [part*4 + octet], B [octet*3 + part] (the order the split weights are stored in).
+    constexpr int LG = BX ? 12 : KG;
+    constexpr int LP = BX ? 2 : 1;     // row padding: BX writes 8-byte halves, pitch = 2 mod 16 keeps them apart
+    constexpr int A_F4 = 2 * LG * (BM + LP);
+    constexpr int B_F4 = 2 * LG * (BN + LP);
     __shared__ f32x4 smem[KGRP * (A_F4 + B_F4)];
     const int grp = KGRP == 1 ? 0 : (int)(threadIdx.x / GT);
-    f32x4 (*As)[KG][BM + 1] = reinterpret_cast<f32x4 (*)[KG][BM + 1]>(&smem[grp * (A_F4 + B_F4)]);
-    f32x4 (*Bs)[KG][BN + 1] = reinterpret_cast<f32x4 (*)[KG][BN + 1]>(&smem[grp * (A_F4 + B_F4) + A_F4]);
+    f32x4 (*As)[LG][BM + LP] = reinterpret_cast<f32x4 (*)[LG][BM + LP]>(&smem[grp * (A_F4 + B_F4)]);
+    f32x4 (*Bs)[LG][BN + LP] = reinterpret_cast<f32x4 (*)[LG][BN + LP]>(&smem[grp * (A_F4 + B_F4) + A_F4]);
 
     const aldm_igemm_desc& d = p.d;
     const int tid = KGRP == 1 ? (int)threadIdx.x : (int)(threadIdx.x % GT);  // position inside the wave group
@@ -126,7 +157,8 @@ void igemm_kernel(const IgemmK p) {
     const int split = blockIdx.y;
     const float* x1 = d.x1 + (int64_t)z * d.stride_x;
     const float* x2 = d.x2 ? d.x2 + (int64_t)z * d.stride_x : x1;
-    const float* wgt = d.w + (int64_t)z * d.stride_w;
+    // BX: the weights arrive pre-split into bf16 parts (aldm_pack_split_bf16), one shared matrix
+    const float* wgt = BX ? reinterpret_cast<const float*>(d.w_split) : d.w + (int64_t)z * d.stride_w;
 
     const int nk_all = (d.K + BK - 1) / BK;
     const int kt0 = split * p.kt_per_split;
@@ -172,14 +204,16 @@ void igemm_kernel(const IgemmK p) {
     // it is stored at Bs[buf][b_skg + pp*b_skgs][b_sc + pp*b_scs].
     //   PACKED [Kg][Npad][4]: thread -> column tid % BN, k-groups tid / BN + (GT/BN)*pp
     //   NT     Bmat[N][ldb] : thread -> row tid / 8 + RPP*pp, k-group tid % 8
+    //   BX     [octet][part][Npad][8 bf16]: as PACKED with 12 always-valid 16-byte slots per k-tile (the
+    //          split weights are zero padded to whole k-tiles)
     constexpr int stepb = GT / BN;
-    const bool packed = d.b_mode == ALDM_B_PACKED;
-    const int64_t b_kt = packed ? (int64_t)KG * p.Npad * 4 : BK;
+    const bool packed = BX || d.b_mode == ALDM_B_PACKED;
+    const int64_t b_kt = packed ? (int64_t)LG * p.Npad * 4 : BK;
     const int64_t b_pp = packed ? (int64_t)stepb * p.Npad * 4 : (int64_t)RPP * d.ldb;
     const int64_t b_base = packed ? ((int64_t)(tid / BN) * p.Npad + n0 + tid % BN) * 4
                                   : (int64_t)(n0 + ar0) * d.ldb + 4 * akg;
-    const int b_ks = packed ? KG : BK, b_kps = packed ? stepb : 0;
-    const int b_k0 = packed ? tid / BN : 4 * akg, b_klim = packed ? p.Kg : d.K;
+    const int b_ks = BX ? 0 : (packed ? KG : BK), b_kps = BX ? 0 : (packed ? stepb : 0);
+    const int b_k0 = BX ? 0 : (packed ? tid / BN : 4 * akg), b_klim = BX ? 1 : (packed ? p.Kg : d.K);
     const int b_nps = packed ? 0 : RPP, b_n0 = packed ? n0 + tid % BN : n0 + ar0;
     const int b_nlim = packed ? p.Npad : d.N;
     const int b_skg = packed ? tid / BN : akg, b_skgs = packed ? stepb : 0;
@@ -321,11 +355,43 @@ void igemm_kernel(const IgemmK p) {
             }
         }
         if (!((r.avalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // zero padding stays zero
-        As[buf][akg][ar0 + RPP * pp] = v;
+        if constexpr (BX) {
+            // exact 3-way split x = hi + mid + lo, each part the top 16 bits of an fp32 (8 significant bits,
+            // truncation: the parts cover x's 24-bit significand exactly); two parts packed per dword
+            unsigned u0[4], u1[4], u2[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float x = v[c];  // (bit-casting the vector element directly reads element 0 on this compiler)
+                u0[c] = __builtin_bit_cast(unsigned, x);
+                const float r1 = x - __builtin_bit_cast(float, u0[c] & 0xFFFF0000u);
+                u1[c] = __builtin_bit_cast(unsigned, r1);
+                const float r2 = r1 - __builtin_bit_cast(float, u1[c] & 0xFFFF0000u);
+                u2[c] = __builtin_bit_cast(unsigned, r2);
+            }
+#if ALDM_ABLATE & 4
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u1[c] = u2[c] = u0[c];
+#endif
+            const int o = akg >> 1, hf = akg & 1, row = ar0 + RPP * pp;
+#if ALDM_ABLATE & 8
+            asm volatile("" ::"v"(u0[0]), "v"(u0[1]), "v"(u0[2]), "v"(u0[3]), "v"(u1[0]), "v"(u1[1]), "v"(u1[2]), "v"(u1[3]));
+            asm volatile("" ::"v"(u2[0]), "v"(u2[1]), "v"(u2[2]), "v"(u2[3]));
+            return;
+#endif
+            reinterpret_cast<u32x2*>(&As[buf][0 + o][row])[hf] = u32x2{hi16_pair(u0[0], u0[1]), hi16_pair(u0[2], u0[3])};
+            reinterpret_cast<u32x2*>(&As[buf][4 + o][row])[hf] = u32x2{hi16_pair(u1[0], u1[1]), hi16_pair(u1[2], u1[3])};
+            reinterpret_cast<u32x2*>(&As[buf][8 + o][row])[hf] = u32x2{hi16_pair(u2[0], u2[1]), hi16_pair(u2[2], u2[3])};
+        } else {
+            As[buf][akg][ar0 + RPP * pp] = v;
+        }
     };
     auto store_b = [&](Stage& r, int buf, int pp) {
         f32x4 v = r.rb[pp];
         if (!((r.bvalid >> pp) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#if ALDM_ABLATE & 16
+        asm volatile("" ::"v"(v));
+        return;
+#endif
         Bs[buf][b_skg + pp * b_skgs][b_sc + pp * b_scs] = v;
     };
     auto commit = [&](Stage& r, int buf) {
@@ -352,8 +418,58 @@ void igemm_kernel(const IgemmK p) {
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    // one half of a k-tile = 2 sub-steps of 8 k: one ds_read_b128 per fragment, 4 MFMAs per fragment
-    // pair and tile
+    // BX: fragments of one 16-wide k-step (lane half lh owns k-octet 2*step + lh of both operands, the same
+    // 8 k on both sides) and their product: fp32 a*b = 6 bf16 partial products, smallest first, accumulated
+    // in fp32 by the MFMA.  Reading and multiplying are separate so the K loop can keep one step of
+    // fragments in flight behind the other step's MFMAs.
+    struct Frag {
+        bf16x8 a[MT][3], b[NT][3];
+    };
+    auto read_frags = [&](Frag& f, int buf, int step) {
+        if constexpr (!BX) return;
+        const int o = 2 * step + lh;
+#if !(ALDM_ABLATE & 2)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                f.a[i][q] = __builtin_bit_cast(bf16x8, As[buf][q * 4 + o][(wm * MT + i) * 32 + l31]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                f.b[j][q] = __builtin_bit_cast(bf16x8, Bs[buf][o * 3 + q][(wn * NT + j) * 32 + l31]);
+#endif
+    };
+    auto mma_frags = [&](Frag& f) {
+        if constexpr (!BX) return;
+#if ALDM_ABLATE & 2
+        return;
+#elif ALDM_ABLATE & 1
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.a[i][q]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.b[j][q]));
+        return;
+#else
+        constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j],
+                                                                        0, 0, 0);
+#endif
+    };
+
+    // fp32 MFMA: one half of a k-tile = 2 sub-steps of 8 k: one ds_read_b128 per fragment, 4 MFMAs per
+    // fragment pair and tile
     auto mma_half = [&](int buf, int half) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -378,22 +494,89 @@ void igemm_kernel(const IgemmK p) {
         // (and barriers), an iteration without a tile only synchronises
         const int n_it = (kt1 - kt0 + KGRP - 1) / KGRP;
         auto tile_of = [&](int it) { return kt0 + grp + it * KGRP; };
-        Stage r0;
-        if (tile_of(0) < kt1) {
-            issue_loads(r0);
-            commit(r0, 0);
-        }
-        __syncthreads();
-        int buf = 0;
-        for (int it = 0; it < n_it; ++it) {
-            const bool cur = tile_of(it) < kt1, nxt = tile_of(it + 1) < kt1;
-            if (nxt) issue_loads(r0);
-            if (cur) mma_half(buf, 0);
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use behind half the MFMAs
-            if (nxt) commit(r0, buf ^ 1);
-            if (cur) mma_half(buf, 1);
-            if (it + 1 < n_it) __syncthreads();
-            buf ^= 1;
+        if constexpr (!BX) {
+            Stage r0;
+            if (tile_of(0) < kt1) {
+                issue_loads(r0);
+                commit(r0, 0);
+            }
+            __syncthreads();
+            int buf = 0;
+            for (int it = 0; it < n_it; ++it) {
+                const bool cur = tile_of(it) < kt1, nxt = tile_of(it + 1) < kt1;
+                if (nxt) issue_loads(r0);
+                if (cur) mma_half(buf, 0);
+                __builtin_amdgcn_sched_barrier(0);  // keep the loads' first use behind half the MFMAs
+                if (nxt) commit(r0, buf ^ 1);
+                if (cur) mma_half(buf, 1);
+                if (it + 1 < n_it) __syncthreads();
+                buf ^= 1;
+            }
+        } else {
+            // BX: a k-tile's MFMAs last 768 (8-wave tile) .. 1536 cycles - less than a global load's latency and
+            // about as long as the tile's LDS traffic - so everything is software pipelined inside the wave:
+            //  * global loads run TWO k-tiles ahead in two register stages (iteration `it` issues tile it+2,
+            //    commits tile it+1, multiplies tile it);
+            //  * the fragments of k-step 1 are read while k-step 0's MFMAs run, and - after the barrier that
+            //    publishes the next buffer - the next tile's k-step 0 fragments while k-step 1's MFMAs run.
+            // `steady` iterations (tiles it .. it+2 exist for every wave group) are branch-free: a conditional
+            // issue_loads makes the compiler's s_waitcnt insertion assume the committed stage holds the
+            // newest loads and drain the whole queue (vmcnt(0)), i.e. no prefetch at all.
+            Stage r0, r1;
+            Frag f0, f1;
+            if (tile_of(0) < kt1) issue_loads(r0);
+            if (tile_of(1) < kt1) issue_loads(r1);
+            if (tile_of(0) < kt1) commit(r0, 0);
+            __syncthreads();
+            if (tile_of(0) < kt1) read_frags(f0, 0, 0);
+            auto body = [&](Stage& ld, Stage& cm, int it, int buf, auto steady) {
+                constexpr bool ST = decltype(steady)::value;
+                const bool cur = ST || tile_of(it) < kt1, nxt = ST || tile_of(it + 1) < kt1;
+                const bool nx2 = ST || tile_of(it + 2) < kt1;
+                if (nx2) issue_loads(ld);
+                __builtin_amdgcn_sched_barrier(0);
+                if (cur) read_frags(f1, buf, 1);
+                if (cur) mma_frags(f0);
+                if (nxt) commit(cm, buf ^ 1);
+                if constexpr (ST && ALDM_BX_INTERLEAVE) {
+                    // one wave's MFMA stream leaves ~28 of every 32 cycles of its issue slot free: spread the
+                    // k-step-1 fragment reads and the commit (prologue + split VALU, LDS stores) between the
+                    // MFMAs instead of running them as separate phases
+                    constexpr int NMF = 6 * MT * NT, NRD = 3 * (MT + NT);
+                    constexpr int NVA = PA * (PRE == PRE_AFFINE_SILU ? 84 : (PRE == PRE_NONE ? 32 : 44)) + 8;
+                    constexpr int VPM = (NVA + NMF - 1) / NMF, NWR = 3 * PA + PB;
+#pragma unroll
+                    for (int q = 0; q < NMF; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                        if (q >= NMF - NWR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ST || it + 1 < n_it) __syncthreads();  // everyone has read `buf` and written `buf ^ 1`
+                if (nxt) read_frags(f0, buf ^ 1, 0);
+                if (cur) mma_frags(f1);
+                if constexpr (ST && ALDM_BX_INTERLEAVE) {
+                    constexpr int NMF = 6 * MT * NT, NRD = 3 * (MT + NT);
+#pragma unroll
+                    for (int q = 0; q < NMF; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                        if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int n_full = (kt1 - kt0) / KGRP;  // iterations in which every wave group has a tile
+            int it = 0;
+            for (; it + 3 < n_full; it += 2) {
+                body(r0, r1, it, 0, std::true_type{});
+                body(r1, r0, it + 1, 1, std::true_type{});
+            }
+            for (; it < n_it; it += 2) {  // `it` is even here: same stage roles as in the steady loop
+                body(r0, r1, it, 0, std::false_type{});
+                if (it + 1 < n_it) body(r1, r0, it + 1, 1, std::false_type{});
+            }
         }
     }
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALDM_LIB_PATH") or os.path.join(_HERE, "libaldm_hip.so")  # override: debug builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
 B_PACKED, B_NT = 0, 1
@@ -44,6 +44,7 @@ class IgemmDesc(C.Structure):
         ("rowbias_ld", C.c_int32), ("epi_mode", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("hint_bm", C.c_int32), ("hint_bn", C.c_int32), ("hint_splits", C.c_int32), ("hint_kgroups", C.c_int32),
+        ("w_split", C.c_void_p), ("hint_mma", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -52,10 +53,14 @@ _SIGS = {
     "aldm_last_error": (C.c_char_p, []),
     "aldm_igemm": (C.c_int, [C.POINTER(IgemmDesc), C.c_void_p]),
     "aldm_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                  C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
     "aldm_igemm_ws_floats": (C.c_int64, [C.POINTER(IgemmDesc)]),
     "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "aldm_igemm_wave8_mask": (C.c_int, [C.c_int]),
+    "aldm_igemm_mma": (C.c_int, [C.c_int]),
+    "aldm_split_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "aldm_pack_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_kn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

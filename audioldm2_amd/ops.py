@@ -32,19 +32,52 @@ def _chk(t: torch.Tensor, name: str):
                            f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
+# Matrix-core path of the igemm engine: "f32" = fp32 MFMA (v_mfma_f32_32x32x2_f32), "bf16x6" = fp32 product as
+# 6 bf16 partial products of exact 3-way operand splits on the bf16 matrix cores, fp32 accumulate (fp32-grade
+# error).  $ALDM_MMA picks the default; set_mma() switches at run time (packed weights
+# build their split image lazily on first use).
+MMA_MODE = os.environ.get("ALDM_MMA", "f32")
+assert MMA_MODE in ("f32", "bf16x6"), MMA_MODE
+
+
+def set_mma(mode: str) -> str:
+    """Select the matrix-core path for subsequent igemm launches ("f32" | "bf16x6"); returns the previous one.
+    Captured HIP graphs keep the path they were captured with."""
+    global MMA_MODE
+    assert mode in ("f32", "bf16x6"), mode
+    prev, MMA_MODE = MMA_MODE, mode
+    return prev
+
+
 @dataclass
 class Packed:
-    """A weight re-laid-out once for the igemm B operand: [ceil(K/4)][Npad][4]."""
+    """A weight re-laid-out once for the igemm B operand: [ceil(K/4)][Npad][4], plus — in
+    "bf16x6" mode — its bf16-split image [4*ceil(K/32)][3][Npad][8 bf16] (aldm_pack_split_bf16)."""
     data: torch.Tensor
     N: int
     Cin: int
     KH: int
     KW: int
     bias: Optional[torch.Tensor] = None
+    split: Optional[torch.Tensor] = None
 
     @property
     def K(self) -> int:
         return self.KH * self.KW * self.Cin
+
+    def split_ptr(self) -> Optional[int]:
+        """Device pointer of the bf16-split image (built on first use) or None in fp32 mode."""
+        if MMA_MODE != "bf16x6":
+            return None
+        if self.split is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # never allocate inside a capture: this launch stays on the fp32 MFMA
+            lib = _l.load()
+            self.split = torch.empty(lib.aldm_split_bytes(self.K, self.N) // 4, device=self.data.device,
+                                     dtype=torch.int32)
+            _l.check(lib.aldm_pack_split_bf16(self.data.data_ptr(), self.split.data_ptr(), self.K, self.N,
+                                              _stream()), "pack_split_bf16")
+        return self.split.data_ptr()
 
 
 # Optional profiling hook (bench.py's roofline leg): when PROFILE is a list, every igemm launch is
@@ -93,16 +126,18 @@ def tune_key(d: IgemmDesc) -> str:
     return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}"
 
 
-def _tuned_table():
+def _tuned_table(bx: bool = False):
+    """{geometry key: [BM, BN, splits, kgroups(, mma)]} for the fp32-MFMA (bx=False) or bf16-split launches."""
     global _TUNED
     if _TUNED is None:
-        _TUNED = {}
+        _TUNED = {False: {}, True: {}}
         if os.environ.get("ALDM_NO_TUNING", "0") != "1":
-            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "mi355x_igemm.json")
-            if os.path.exists(path):
-                with open(path) as f:
-                    _TUNED = {k: v[:4] for k, v in json.load(f)["entries"].items()}
-    return _TUNED
+            for mode, name in ((False, "mi355x_igemm.json"), (True, "mi355x_igemm_bf16x6.json")):
+                path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", name)
+                if os.path.exists(path):
+                    with open(path) as f:
+                        _TUNED[mode] = {k: v[:5] if mode else v[:4] for k, v in json.load(f)["entries"].items()}
+    return _TUNED[bx]
 
 
 def _igemm(d: IgemmDesc, what: str, device=None):
@@ -110,15 +145,17 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     key = tune_key(d)
     if TUNE_LOG is not None:
         TUNE_LOG.append(key)
-    hint = _tuned_table().get(key)
+    hint = _tuned_table(bool(d.w_split)).get(key)
     if hint is not None:
-        d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = hint
+        d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = hint[:4]
+        d.hint_mma = hint[4] if len(hint) > 4 else 0  # bf16x6 table: 1 = this shape is faster on the fp32 MFMA
     _workspace(lib, d, device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     if PROFILE is None:
         _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
         return
-    bm, bn, fl, sp, kg = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int()
-    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl), C.byref(sp), C.byref(kg)), what)
+    bm, bn, fl, sp, kg, mma = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int(), C.c_int()
+    _l.check(lib.aldm_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(fl), C.byref(sp), C.byref(kg),
+                                 C.byref(mma)), what)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -126,7 +163,8 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     e1.record()
     shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch,
              sp.value * 10 + kg.value)
-    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape, _kernel_name(d, bm.value, bn.value, kg.value)))
+    PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape,
+                    _kernel_name(d, bm.value, bn.value, kg.value, bool(mma.value))))
 
 
 def _pre_mode(d: IgemmDesc) -> int:
@@ -142,24 +180,31 @@ def _pre_mode(d: IgemmDesc) -> int:
     return 4
 
 
-def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1) -> str:
+def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) -> str:
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
-    (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI>)."""
+    (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
     pre = _pre_mode(d)
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     # 8 waves per tile: same rule as csrc/igemm.hip (ALDM_IGEMM_W8 tile mask, default 128x128 GroupNorm prologues)
     w8 = _wave8_mask if _wave8_mask >= 0 else int(os.environ.get("ALDM_IGEMM_W8", "1"))
     bit = {(128, 128): 1, (64, 128): 2, (128, 64): 4}.get((bm, bn), 0)
-    if kg == 1 and d.epi_mode != _l.EPI_GEGLU and (w8 & bit) and (pre in (1, 2) or (bit == 1 and (w8 & 8))):
+    if kg == 1 and d.epi_mode != _l.EPI_GEGLU and (w8 & bit) and (
+            bit == 1 if bx else (pre in (1, 2) or (bit == 1 and (w8 & 8)))):
         wm, wn = (4, 2) if bit == 4 else (2, 4)
     uni = "true" if pre in (1, 2) and (d.OH * d.OW) % bm == 0 else "false"
-    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {pre}, {kg}, {uni}>"
+    return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {pre}, {kg}, {uni}, {'true' if bx else 'false'}>"
 
 
 def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0) -> None:
     """Tuning override for tools/tests: force tile / split-K / wave groups of subsequent igemm launches
     (bm = 0: automatic)."""
     _l.load().aldm_igemm_force(bm, bn, splits, kgroups)
+
+
+def igemm_mma(mode: int) -> int:
+    """Tuning override for tools/tests (aldm_igemm_mma): 0 automatic, 1 fp32 MFMA always, 2 bf16-split wherever an
+    instantiation exists.  Returns the previous mode."""
+    return _l.load().aldm_igemm_mma(mode)
 
 
 _wave8_mask = -1
@@ -221,7 +266,7 @@ def linear_geglu(x: torch.Tensor, pw: Packed) -> torch.Tensor:
     d.x1 = x.data_ptr(); d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
-    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N; d.w_split = pw.split_ptr()
     d.bias = _p(pw.bias); d.out = out.data_ptr(); d.ldo = pw.N // 2; d.alpha = 1.0
     d.epi_mode = _l.EPI_GEGLU; d.batch = 1
     _igemm(d, "igemm(geglu)")
@@ -294,7 +339,7 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     if pre is not None:
         d.pre_scale = pre[0].data_ptr(); d.pre_shift = pre[1].data_ptr()
     d.pre_act = pre_act; d.pre_slope = pre_slope
-    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0; d.w_split = pw.split_ptr()
     d.K = pw.K; d.N = N
     d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = out.data_ptr()
     if rowbias is not None:

@@ -68,6 +68,8 @@ enum {
  * openaimodel.py:244-250,537-541), F.conv1d DFT basis (stft.py:67-72), torch.bmm
  * (model.py:219,226), torch.matmul mel basis (stft.py:174).
  */
+enum { ALDM_MMA_F32 = 0, ALDM_MMA_BF16X6 = 1 };
+
 typedef struct aldm_igemm_desc {
     /* A operand: gathered input */
     const float* x1;       /* [B, H, W, C1] channels-last                                   */
@@ -120,6 +122,13 @@ typedef struct aldm_igemm_desc {
     int32_t hint_bm, hint_bn, hint_splits;
     int32_t hint_kgroups;  /* 2 = two 4-wave groups per block share the 64x64 tile's K loop (in-block
                               split-K through LDS: no workspace, no reduce kernel); 0/1 = one group */
+    /* ABI v4: optional bf16-split image of the packed weights (aldm_pack_split_bf16).  When set (packed
+       weights, stride_w == 0) the product runs on the bf16 matrix cores as fp32 = 6 bf16 partial products
+       of exact 3-way operand splits with fp32 accumulation ("BF16x6": per-product error <= 2^-23, i.e. fp32
+       grade) instead of the fp32 MFMA.  NULL => fp32 MFMA.                         */
+    const void* w_split;
+    int32_t hint_mma;      /* tuned table: 1 = fp32 MFMA even when w_split is set, 0 = automatic          */
+    int32_t reserved0;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -131,7 +140,8 @@ int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* d);
 /* Host-only query (no launch): the block tile / split-K factor aldm_igemm would pick for this
  * descriptor and the algorithmic FLOPs of the call (2*M*N*K*batch) — used by bench.py's roofline
  * accounting.  splits / kgroups may be NULL.                                                              */
-int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits, int* kgroups);
+int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits, int* kgroups,
+                    int* mma);   /* mma: ALDM_MMA_* the launch would run on (may be NULL) */
 /* Tuning override (tests / tools): force the block tile and split-K factor of subsequent
  * aldm_igemm calls on this thread; bm = 0 => automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
 void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
@@ -139,6 +149,15 @@ void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
  * tile on this thread (1: 128x128, 2: 64x128, 4: 128x64 — GroupNorm-prologue launches; 8: 128x128 launches
  * without a prologue too).  mask < 0 restores the default (1, or $ALDM_IGEMM_W8).  Returns the mask in force. */
 int aldm_igemm_wave8_mask(int mask);
+/* Matrix-core path override (tests / tools) for this thread: 0 = automatic (bf16-split when the descriptor
+ * carries w_split and the tuned hint allows), 1 = fp32 MFMA always, 2 = bf16-split wherever an instantiation
+ * exists.  Returns the previous mode; other values only query.                                            */
+int aldm_igemm_mma(int mode);
+/* bf16-split image of a packed weight [ceil(K/4)][Npad][4] (aldm_pack_weight / aldm_pack_kn output) for
+ * aldm_igemm_desc.w_split: [4*ceil(K/32) k-octets][3 parts][Npad][8 bf16], w = hi + mid + lo exactly.
+ * aldm_split_bytes = size of that image.                                                                 */
+int64_t aldm_split_bytes(int K, int N);
+int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* stream);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1

@@ -118,7 +118,7 @@ def tune(key, lib):
     d.hint_bm = d.hint_bn = d.hint_splits = d.hint_kgroups = 0
     t_auto = time_launch(lib, d, reps)
     bm0, bn0, fl, sp0, kg0 = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int()
-    lib.aldm_igemm_plan(C.byref(d), C.byref(bm0), C.byref(bn0), C.byref(fl), C.byref(sp0), C.byref(kg0))
+    lib.aldm_igemm_plan(C.byref(d), C.byref(bm0), C.byref(bn0), C.byref(fl), C.byref(sp0), C.byref(kg0), None)
     best = (t_auto, bm0.value, bn0.value, sp0.value, kg0.value)
     geglu = d.epi_mode == L.EPI_GEGLU
     tiles = [(128, 32)] if N <= 32 else TILES
