@@ -202,8 +202,7 @@ static int pre_mode_of(const aldm_igemm_desc& d) {
     return PRE_GENERIC;
 }
 
-static bool tile_supported(int BM, int BN, bool bx) {
-    if (BM == 256 && BN == 128) return bx;  // 8-wave tile of the bf16-split kernels only
+static bool tile_supported(int BM, int BN) {
     return (BM == 128 && (BN == 128 || BN == 64 || BN == 32)) || (BM == 64 && (BN == 128 || BN == 64));
 }
 
@@ -286,7 +285,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
                        pre != PRE_GENERIC && (reinterpret_cast<uintptr_t>(d.w_split) & 15) == 0 &&
                        (g_force_mma == 2 || (g_force_mma == 0 && d.hint_mma != 1));
     auto occ_of = [&](int bm, int bn) {
-        if (bx_ok && bn != 32) return bm * bn >= 128 * 128 ? 1 : (bm * bn >= 64 * 128 ? 2 : 3);  // 256x128: 1
+        if (bx_ok && bn != 32) return bm * bn >= 128 * 128 ? 1 : (bm * bn >= 64 * 128 ? 2 : 3);
         return bm * bn >= 128 * 128 ? 2 : ((bm * bn >= 64 * 128 || bn == 32) ? 3 : 4);
     };
     const double pre_w = (d.pre_scale != nullptr || d.pre_act != ALDM_ACT_NONE) ? 1.5 : 1.0;
@@ -299,7 +298,10 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         const double blocks = (double)cdiv64(Mz, bm) * cdiv(d.N, bn) * d.batch * sp;
         const double L = (double)kt * bm * bn / 4.0 * mf;
         const int o = kg == 2 ? (bx ? 1 : 2) : occ_of(bm, bn);  // 512-thread blocks: two per CU (one with BX)
-        const double S = (300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32)) * (bx ? 1.3 : 1.0);
+        // BX staging: + the operand split, but the 8-wave 128x128 tile halves the per-thread share and its
+        // interleaved schedule hides most of it behind the MFMAs (profiles/r01_mma_ab.txt)
+        const double S = (300.0 * (bm / 32) * pre_w + 200.0 * (bn / 32)) *
+                         (bx ? (bm * bn >= 128 * 128 && !geglu ? 0.45 : 1.3) : 1.0);
         const double F = 4000.0 + (kg == 2 ? 600.0 : 0.0);
         const int64_t nb = (int64_t)((blocks + 255.0) / 256.0);
         const int64_t full = nb / o, last = nb - full * o;
@@ -320,7 +322,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     if (f_bm) {
         BM = f_bm;
         BN = f_bn;
-        ALDM_CHECK(tile_supported(BM, BN, bx_ok), "aldm_igemm: unsupported forced/hinted tile %dx%d", BM, BN);
+        ALDM_CHECK(tile_supported(BM, BN), "aldm_igemm: unsupported forced/hinted tile %dx%d", BM, BN);
         ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: the GEGLU epilogue needs a 128-column tile");
         if (f_sp > 0 && can_split && nk / f_sp >= 1) splits = f_sp;
         if (f_kg == 2) {
@@ -331,12 +333,12 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         BM = 128;
         BN = 32;
     } else {
-        static const int cand[5][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}, {256, 128}};
+        static const int cand[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
         static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
         double best = 1e300;
         BM = 64;
         BN = 64;
-        for (int c = 0; c < (bx_ok ? 5 : 4); ++c) {
+        for (int c = 0; c < 4; ++c) {
             const int bm = cand[c][0], bn = cand[c][1];
             if (geglu ? bn != 128 : (bn > 64 && d.N <= 64)) continue;  // 
             for (int si = 0; si < 8; ++si) {

@@ -16,8 +16,10 @@ int igemm_launch_bx_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 gr
     if (kgroups == 2) {
         if (BM == 64 && BN == 64) ALDM_IG(64, 64, 2, 2, 2);
         else return -1;
-    } else if (BM == 256 && BN == 128) ALDM_IG(256, 128, 4, 2, 1);  // 8 waves, 64x64 per wave, one block per CU
-    else if (BM == 128 && BN == 128 && w8) ALDM_IG(128, 128, 2, 4, 1);  // one block per CU: 8 waves
+    } else if (BM == 128 && BN == 128 && p.d.epi_mode == ALDM_EPI_GEGLU) {
+        if constexpr (PRE == PRE_NONE) ALDM_IG(128, 128, 4, 2, 1);  // 8 waves as 4x2: two 32-column tiles per wave
+        else ALDM_IG(128, 128, 2, 2, 1);                            // (value + gate), what the GEGLU epilogue needs
+    } else if (BM == 128 && BN == 128 && w8) ALDM_IG(128, 128, 2, 4, 1);  // one block per CU: 8 waves
     else if (BM == 128 && BN == 128) ALDM_IG(128, 128, 2, 2, 1);
     else if (BM == 128 && BN == 64) ALDM_IG(128, 64, 2, 2, 1);
     else if (BM == 64 && BN == 128) ALDM_IG(64, 128, 2, 2, 1);

@@ -34,9 +34,9 @@ def _chk(t: torch.Tensor, name: str):
 
 # Matrix-core path of the igemm engine: "f32" = fp32 MFMA (v_mfma_f32_32x32x2_f32), "bf16x6" = fp32 product as
 # 6 bf16 partial products of exact 3-way operand splits on the bf16 matrix cores, fp32 accumulate (fp32-grade
-# error).  $ALDM_MMA picks the default; set_mma() switches at run time (packed weights
-# build their split image lazily on first use).
-MMA_MODE = os.environ.get("ALDM_MMA", "f32")
+# error) - the default: 1.3-1.8x the fp32 MFMA's throughput at the same accuracy.  $ALDM_MMA
+# overrides; set_mma() switches at run time (packed weights build their split image lazily on first use).
+MMA_MODE = os.environ.get("ALDM_MMA", "bf16x6")
 assert MMA_MODE in ("f32", "bf16x6"), MMA_MODE
 
 
@@ -191,6 +191,8 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     if kg == 1 and d.epi_mode != _l.EPI_GEGLU and (w8 & bit) and (
             bit == 1 if bx else (pre in (1, 2) or (bit == 1 and (w8 & 8)))):
         wm, wn = (4, 2) if bit == 4 else (2, 4)
+    if bx and (bm, bn) == (128, 128) and d.epi_mode == _l.EPI_GEGLU and pre == 0:
+        wm, wn = 4, 2  # 8 waves as 4x2 for the GEGLU epilogue (csrc/igemm_bx_pre0.hip)
     uni = "true" if pre in (1, 2) and (d.OH * d.OW) % bm == 0 else "false"
     return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {pre}, {kg}, {uni}, {'true' if bx else 'false'}>"
 

@@ -31,6 +31,9 @@ import torch  # noqa: E402
 UNET_GFLOP_PER_FWD_SAMPLE = {"audioldm2-full": 171.20, "audioldm2-full-large-1150k": 353.69,
                              "audioldm2-speech-gigaspeech": 151.85, "audioldm_48k": 145.40}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# bf16-split kernels ("BF16x6"): one fp32 multiply-add = 6 bf16 MFMA partial products, so their fp32-equivalent
+# matrix-core roofline is the dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, ~2500 TFLOP/s) / 6
+PEAK_BF16X6_TFLOPS = round(2500.0 / 6.0, 1)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
 
 
@@ -42,6 +45,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="prompts per GPU")
     ap.add_argument("--ddim-steps", type=int, default=200)
     ap.add_argument("--model", default="audioldm2-full")
+    ap.add_argument("--mma", choices=["bf16x6", "f32"], default=None,
+                    help="matrix-core path of the igemm engine (default: $ALDM_MMA or the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-probe", action="store_true")
@@ -92,9 +97,15 @@ def roofline_probe(ld, batch, B):
             traffic_src = {"file": "profiles/r01_pmc_traffic.json", "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}
+    bx = kname.endswith("true>")  # igemm_kernel<..., BX>: bf16-split instantiation
+    peak = PEAK_BF16X6_TFLOPS if bx else PEAK_F32_MFMA_TFLOPS
     return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4),
+        "peak_note": ("fp32-equivalent peak of the bf16-split kernels: dense bf16 MFMA 2500 TFLOP/s / 6 partial "
+                      "products per fp32 multiply-add" if bx else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+        "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": round(minb / n),
         "kernel": "aldm::" + kname, "launches_per_unet_pass": n,
         "avg_launch_us": round(sec / n * 1e6, 2), "flops_per_launch_avg": fl / n,
@@ -160,6 +171,9 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
 def main():
     args = parse()
     from audioldm2_amd import dist as adist
+    from audioldm2_amd import ops as aops
+    if args.mma:
+        aops.set_mma(args.mma)
     from audioldm2_amd.pipeline import build_model, make_batch_for_text_to_audio, seed_everything
     rank, world, local = adist.init_distributed()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
@@ -217,6 +231,9 @@ def main():
                                    f"{args.ddim_steps} DDIM steps, CFG 3.5, eta 1.0, n_candidates 1; one step = "
                                    "sample_log + VAE decode + HiFi-GAN + D2H of the waveform; synthetic "
                                    "conditioning, random-init weights, host-CPU RNG noise",
+                       "mma": ("bf16x6: fp32 operands and accumulation, each product evaluated as 6 bf16 MFMA partial "
+                               "products of exact 3-way operand splits (fp32-grade error)" if aops.MMA_MODE == "bf16x6"
+                               else "f32: fp32 MFMA"),
                        "global_batch": gB, "parallelism": f"prompt-sharded replicas x{world}",
                        "weight_broadcast_bytes": bcast_bytes},
         }

@@ -146,3 +146,26 @@ def test_igemm_tuning_table_is_wellformed():
     d = lib.IgemmDesc()
     d.B, d.H, d.W, d.C1, d.KH, d.KW, d.N = 1, 1, 77, 64, 1, 1, 32
     assert len(ops.tune_key(d).split(",")) == len(t["fields"])
+    # the bf16-split table carries one more value per entry: which matrix-core path won (1 = fp32 MFMA)
+    with open(path.replace("mi355x_igemm.json", "mi355x_igemm_bf16x6.json")) as f:
+        tb = json.load(f)
+    assert tb["fields"] == t["fields"] and tb["mma"] == "bf16x6" and len(tb["entries"]) > 0
+    for k, v in tb["entries"].items():
+        assert len(k.split(",")) == len(tb["fields"])
+        assert (v[0], v[1]) in tiles and 1 <= v[2] <= 16 and v[3] in (1, 2) and v[4] in (0, 1)
+    assert ops._tuned_table(True) and all(len(v) == 5 for v in ops._tuned_table(True).values())
+    assert all(len(v) == 4 for v in ops._tuned_table(False).values())
+
+
+def test_packed_weight_split_image_is_lazy_and_mode_gated(monkeypatch):
+    """Packed.split_ptr(): no split image (and no library call) on the fp32-MFMA path; set_mma validates."""
+    import torch
+    from audioldm2_amd import ops
+    pw = ops.Packed(torch.zeros(4), N=1, Cin=4, KH=1, KW=1)
+    prev = ops.set_mma("f32")
+    try:
+        assert pw.split_ptr() is None and pw.split is None
+        with pytest.raises(AssertionError):
+            ops.set_mma("bf16")
+    finally:
+        ops.set_mma(prev)

@@ -78,6 +78,25 @@ def test_unet_matches_reference_fixture(name, cfg, B, H, W, t5):
     assert e < MOD_TOL
 
 
+@pytest.mark.parametrize("name,cfg,B,H,W,t5", [("unet_tiny", cases.UNET_TINY, 2, 16, 8, 12),
+                                                ("unet_film_tiny", cases.UNET_FILM_TINY, 2, 8, 16, 12)])
+def test_unet_matches_reference_fixture_on_fp32_mfma_path(name, cfg, B, H, W, t5):
+    """The default matrix-core path is the bf16-split one (every other model test); the plain fp32-MFMA kernels
+    (ALDM_MMA=f32) stay a supported configuration and meet the same fixtures."""
+    from audioldm2_amd import ops
+    from audioldm2_amd.unet import UNetModel
+    prev = ops.set_mma("f32")
+    try:
+        m = load_det(UNetModel(**cfg))
+        x, t, ctxs, masks, y = cases.unet_inputs(cfg, B, H, W, t5)
+        out = m(x.cuda(), t.cuda(), y=cu(y), context_list=cu(ctxs), context_attn_mask_list=cu(masks))
+    finally:
+        ops.set_mma(prev)
+    e = rel(out, gold(name)["out"])
+    report(f"{name} (fp32 MFMA path): max-norm rel err vs reference fixture {e:.2e}")
+    assert e < MOD_TOL
+
+
 def test_unet_full_vs_oracle_batch8_properties():
     """BASELINE batch (8 prompts, CFG => 16 rows): agrees with the CPU oracle on two rows, is
     batch-invariant (row b of the batch-16 pass == the same row run alone) and deterministic."""

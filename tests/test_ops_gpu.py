@@ -93,7 +93,7 @@ def test_conv_fused_prologue_epilogue(ops):
     assert rel_err(uncl(y), ref) < GEMM_TOL
 
 
-@pytest.mark.parametrize("bm,bn", [(128, 128), (128, 64), (64, 128), (64, 64), (128, 32), (256, 128)])
+@pytest.mark.parametrize("bm,bn", [(128, 128), (128, 64), (64, 128), (64, 64), (128, 32)])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_igemm_every_tile_and_splitk(ops, bm, bn, splits):
     """Every block-tile instantiation, with and without split-K (partial tiles -> workspace ->
@@ -108,10 +108,6 @@ def test_igemm_every_tile_and_splitk(ops, bm, bn, splits):
     pw = ops.pack_conv(w, b)
     ops.igemm_force(bm, bn, splits)
     try:
-        if (bm, bn) == (256, 128) and ops.MMA_MODE == "f32":  # that tile exists for the bf16-split kernels only
-            with pytest.raises(RuntimeError, match="unsupported forced/hinted tile"):
-                ops.conv(cl(x), pw, pad=(1, 1))
-            return
         y1 = ops.conv(cl(x), pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res))
         y2 = ops.conv(cl(x), pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res))
     finally:
@@ -241,6 +237,24 @@ def test_linear_geglu_fused(ops, M, C, inner):
     ref = val * F.gelu(gate)
     y = ops.linear_geglu(x.cuda(), ops.pack_geglu(w, b))
     assert y.shape == (M, inner)
+    assert rel_err(y, ref) < GEMM_TOL
+
+
+@pytest.mark.parametrize("bm,bn", [(128, 128), (64, 128)])
+def test_linear_geglu_forced_tiles(ops, bm, bn):
+    """The GEGLU epilogue on both 128-column tiles (bf16-split path: the 128x128 tile runs 8 waves as 4x2)."""
+    M, C, inner = 1000, 256, 512
+    x = torch.randn(M, C, generator=g(1))
+    w = torch.randn(2 * inner, C, generator=g(2)) / math.sqrt(C)
+    b = torch.randn(2 * inner, generator=g(3))
+    val, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    pw = ops.pack_geglu(w, b)
+    ops.igemm_force(bm, bn, 1)
+    try:
+        y = ops.linear_geglu(x.cuda(), pw)
+    finally:
+        ops.igemm_force(0, 0, 0)
     assert rel_err(y, ref) < GEMM_TOL
 
 

@@ -2,7 +2,9 @@
 write audioldm2_amd/tuning-style JSON.  Geometry keys are collected from one short eager job
 (ops.TUNE_LOG), then each unique key is re-created with synthetic buffers and every candidate is timed
 with events on the launch stream.
-Usage (GPU box): python tools/igemm_autotune.py out.json [model ...]   (default: audioldm2-full)"""
+Usage (GPU box): python tools/igemm_autotune.py [--mma bf16x6] out.json [model ...]   (default: audioldm2-full)
+With --mma bf16x6 the candidates run on the bf16-split kernels and each shape is also timed on the fp32 MFMA with
+its fp32-table configuration; the entry records which path won (5th value: 1 = fp32 MFMA)."""
 import ctypes as C
 import json
 import math
@@ -18,6 +20,11 @@ from audioldm2_amd import lib as L  # noqa: E402
 from audioldm2_amd import ops  # noqa: E402
 from audioldm2_amd.pipeline import build_model, make_batch_for_text_to_audio, seed_everything  # noqa: E402
 
+BX = False
+if "--mma" in sys.argv:
+    i = sys.argv.index("--mma")
+    BX = sys.argv[i + 1] == "bf16x6"
+    del sys.argv[i:i + 2]
 TILES = [(128, 128), (64, 128), (128, 64), (64, 64)]
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 16]
 
@@ -69,6 +76,12 @@ def make_desc(key):
         d.ldb = K
     d.stride_w = wn if batch > 1 and f["b_mode"] == L.B_NT else (wn if batch > 1 else 0)
     d.w = buf(wn * batch).data_ptr()
+    if BX and f["b_mode"] == L.B_PACKED and batch == 1:
+        lib = L.load()
+        sp = torch.empty(lib.aldm_split_bytes(K, N) // 4, device="cuda", dtype=torch.int32)
+        keep.append(sp)
+        L.check(lib.aldm_pack_split_bf16(d.w, sp.data_ptr(), K, N, torch.cuda.current_stream().cuda_stream), "split")
+        d.w_split = sp.data_ptr()
     M = f["B"] * f["OH"] * f["OW"]
     geglu = f["epi_mode"] == L.EPI_GEGLU
     ldo = N // 2 if geglu else N
@@ -115,7 +128,7 @@ def tune(key, lib):
     nk = (K + 31) // 32
     flops = 2.0 * M * N * K * max(d.batch, 1)
     reps = 3 if flops > 2e10 else 8
-    d.hint_bm = d.hint_bn = d.hint_splits = d.hint_kgroups = 0
+    d.hint_bm = d.hint_bn = d.hint_splits = d.hint_kgroups = d.hint_mma = 0
     t_auto = time_launch(lib, d, reps)
     bm0, bn0, fl, sp0, kg0 = C.c_int(), C.c_int(), C.c_int64(), C.c_int(), C.c_int()
     lib.aldm_igemm_plan(C.byref(d), C.byref(bm0), C.byref(bn0), C.byref(fl), C.byref(sp0), C.byref(kg0), None)
@@ -142,11 +155,30 @@ def tune(key, lib):
                 t = time_launch(lib, d, reps)
                 if t is not None and t < best[0]:
                     best = (t, bm, bn, sp, kg)
+    best = best + (0,)
+    if BX and d.w_split:
+        # the same shape on the fp32 MFMA with its own tuned configuration
+        h = F32_TABLE.get(key, [0, 0, 0, 0])
+        d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = h[:4]
+        d.hint_mma = 1
+        t = time_launch(lib, d, reps)
+        if t is not None and t < 0.97 * best[0]:
+            best = (t, h[0], h[1], h[2], h[3], 1)
     return t_auto, best, (bm0.value, bn0.value, sp0.value, kg0.value), flops
 
 
+F32_TABLE = {}
+
+
 def main():
+    global F32_TABLE
     out = sys.argv[1]
+    if BX:
+        ops.set_mma("bf16x6")
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audioldm2_amd", "tuning",
+                            "mi355x_igemm.json")
+        with open(path) as f:
+            F32_TABLE = json.load(f)["entries"]
     models = sys.argv[2:] or ["audioldm2-full"]
     lib = L.load()
     entries, report = {}, []
@@ -161,9 +193,10 @@ def main():
         t_auto, best, auto_cfg, flops = tune(key, lib)
         total += t_auto * n
         if best[0] < 0.97 * t_auto:
-            entries[key] = [best[1], best[2], best[3], best[4], round(best[0], 1), round(t_auto, 1)]
+            entries[key] = ([best[1], best[2], best[3], best[4]] + ([best[5]] if BX else []) +
+                            [round(best[0], 1), round(t_auto, 1)])
             saved += (t_auto - best[0]) * n
-        report.append(f"{key} n={n} auto {auto_cfg} {t_auto:.1f}us -> best ({best[1]},{best[2]},{best[3]},{best[4]}) {best[0]:.1f}us"
+        report.append(f"{key} n={n} auto {auto_cfg} {t_auto:.1f}us -> best ({best[1]},{best[2]},{best[3]},{best[4]},mma={best[5]}) {best[0]:.1f}us"
                       f" {flops/best[0]/1e6:.1f} TF")
         print(report[-1], flush=True)
     print(f"# {len(entries)} of {len(counts)} geometries tuned; {saved/1e3:.2f} ms saved of {total/1e3:.2f} ms per 2-step job"
@@ -171,7 +204,9 @@ def main():
     with open(out, "w") as f:
         json.dump({"device": torch.cuda.get_device_name(0), "models": models,
                    "fields": list(ops._TUNE_FIELDS) + ["pre_mode"],
-                   "note": "value = [BM, BN, splits, kgroups, tuned_us, cost_model_us]", "entries": entries}, f, indent=0)
+                   "mma": "bf16x6" if BX else "f32",
+                   "note": ("value = [BM, BN, splits, kgroups, mma (1 = fp32 MFMA), tuned_us, cost_model_us]" if BX else
+                            "value = [BM, BN, splits, kgroups, tuned_us, cost_model_us]"), "entries": entries}, f, indent=0)
 
 
 if __name__ == "__main__":
