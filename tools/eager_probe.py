@@ -1,0 +1,31 @@
+"""Eager (no HIP graph) UNet pass, both matrix-core paths: wall time per pass and the host-side enqueue time
+(python returns before the GPU is done) - tells a launch-bound pass from a GPU-bound one."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audioldm2_amd import ops  # noqa: E402
+from audioldm2_amd.unet import UNetModel  # noqa: E402
+from oracle import cases  # noqa: E402
+
+cfg = cases.UNET_FULL
+torch.manual_seed(0)
+m = UNetModel(**cfg).cuda().eval()
+x, t, ctxs, masks, _ = cases.unet_inputs(cfg, 16, 256, 16, 32, seed=4)
+xg, tg = x.cuda(), t.cuda()
+cg, mg = [c.cuda() for c in ctxs], [k.cuda() for k in masks]
+for mode in ("f32", "bf16x6", "f32", "bf16x6"):
+    ops.set_mma(mode)
+    with torch.no_grad():
+        m(xg, tg, context_list=cg, context_attn_mask_list=mg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m(xg, tg, context_list=cg, context_attn_mask_list=mg)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    print(f"{mode}: enqueue {(t1 - t0) / 3 * 1e3:.1f} ms/pass, wall {(t2 - t0) / 3 * 1e3:.1f} ms/pass", flush=True)
