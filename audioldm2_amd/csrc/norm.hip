@@ -14,6 +14,7 @@ namespace aldm {
 // Pass 2: grid (B).  double-precision combine of the chunk partials, mean/rstd, then
 //         scale[b,c] = rstd*gamma[c], shift[b,c] = beta[c] - mean*rstd*gamma[c].
 constexpr int GN_ITERS = 16;
+constexpr int GN_UNROLL = 8;  // pixel loads in flight per thread
 
 // FUSED: one block covers a whole (small) sample, keeps the group sums in LDS and finalises in the
 // same launch — for the deep UNet levels (P <= 256 pixels) the two-launch form is pure latency.
@@ -52,10 +53,33 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             const bool first = c < C1;
             const float* src = first ? x1 + (int64_t)b * P * C1 + c : x2 + (int64_t)b * P * C2 + (c - C1);
             const int pitch = first ? C1 : C2;
-            for (int p = p0 + ty; p < p1; p += rows) {
+            // GN_UNROLL independent loads in flight per thread: with one load per trip the fused form (one
+            // block per sample, a thread walks up to 256 pixels) was a chain of ~130 ns round trips, 34 us
+            // for 650 KB.  Fixed accumulator assignment and combine order -> still deterministic.
+            float sa[GN_UNROLL], sq[GN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < GN_UNROLL; ++u) sa[u] = sq[u] = 0.f;
+            int p = p0 + ty;
+            for (; p + (GN_UNROLL - 1) * rows < p1; p += GN_UNROLL * rows) {
+                f32x4 v[GN_UNROLL];
+#pragma unroll
+                for (int u = 0; u < GN_UNROLL; ++u)
+                    v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + u * rows) * pitch);
+#pragma unroll
+                for (int u = 0; u < GN_UNROLL; ++u) {
+                    sa[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+                    sq[u] += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+                }
+            }
+            for (; p < p1; p += rows) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)p * pitch);
-                s += (v[0] + v[1]) + (v[2] + v[3]);
-                ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                sa[0] += (v[0] + v[1]) + (v[2] + v[3]);
+                sq[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+#pragma unroll
+            for (int u = 0; u < GN_UNROLL; u += 2) {
+                s += sa[u] + sa[u + 1];
+                ss += sq[u] + sq[u + 1];
             }
         }
         ps[tid][0] = s;
