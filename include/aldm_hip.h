@@ -124,7 +124,7 @@ typedef struct aldm_igemm_desc {
                               split-K through LDS: no workspace, no reduce kernel); 0/1 = one group */
     /* ABI v4: optional bf16-split image of the packed weights (aldm_pack_split_bf16).  When set (packed
        weights, stride_w == 0) the product runs on the bf16 matrix cores as fp32 = 6 bf16 partial products
-       of exact 3-way operand splits with fp32 accumulation ("BF16x6": per-product error <= 2^-23, i.e. fp32
+       of exact 3-way operand splits with fp32 accumulation ("BF16x6": per-product error 0.7 * 2^-24 on average, <= 2^-21 worst case, i.e. fp32
        grade) instead of the fp32 MFMA.  NULL => fp32 MFMA.                         */
     const void* w_split;
     int32_t hint_mma;      /* tuned table: 1 = fp32 MFMA even when w_split is set, 0 = automatic          */

@@ -258,6 +258,28 @@ def test_linear_geglu_forced_tiles(ops, bm, bn):
     assert rel_err(y, ref) < GEMM_TOL
 
 
+def test_weight_split_image_is_bit_exact_vs_numpy_restatement(ops):
+    """aldm_pack_weight + aldm_pack_split_bf16 against oracle/bf16x6.py, bit for bit: layout [k-octet][part][Npad][8]
+    and the exact hi/mid/lo truncation split (ragged K and N: zero padding to whole k-tiles / 32 columns)."""
+    import numpy as np
+    from oracle import bf16x6 as bx
+    N, Cin, KH, KW = 40, 12, 2, 3  # K = 72
+    w = torch.randn(N, Cin, KH, KW, generator=g(11)) * 0.05
+    prev = ops.set_mma("bf16x6")
+    try:
+        pw = ops.pack_conv(w)
+        assert pw.split_ptr() is not None
+        img = pw.split.cpu().numpy().view(np.uint16)
+    finally:
+        ops.set_mma(prev)
+    K = Cin * KH * KW
+    w_kn = w.permute(2, 3, 1, 0).reshape(K, N).numpy()  # k = (kh*KW + kw)*Cin + ci
+    packed = bx.pack_kn(w_kn)
+    assert np.array_equal(pw.data.cpu().numpy().reshape(packed.shape), packed)
+    ref = bx.split_image(packed, K)
+    assert img.size == ref.size and np.array_equal(img.reshape(ref.shape), ref)
+
+
 def test_conv_upsample_nearest(ops):
     B, C, H, W = 2, 64, 8, 4
     x = torch.randn(B, C, H, W, generator=g(1))
