@@ -86,3 +86,73 @@ def test_hot_modules_refuse_cpu_tensors():
     x, t, ctxs, masks, y = cases.unet_inputs(cases.UNET_TINY, 1, 8, 8)
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(x, t, context_list=ctxs, context_attn_mask_list=masks)
+
+
+def _plan(l, lib, d):
+    bm, bn, sp, kg, mma = (ctypes.c_int() for _ in range(5))
+    fl = ctypes.c_int64()
+    rc = l.aldm_igemm_plan(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(fl), ctypes.byref(sp),
+                           ctypes.byref(kg), ctypes.byref(mma))
+    lib.check(rc, "plan")
+    return bm.value, bn.value, sp.value, kg.value, mma.value, fl.value
+
+
+def _conv_desc(lib, B=16, H=256, W=16, C=128, N=128, k=3):
+    d = lib.IgemmDesc()
+    d.x1, d.w, d.out = 0x1000, 0x2000, 0x3000  # never dereferenced: the plan query is host-only
+    d.C1, d.B, d.H, d.W = C, B, H, W
+    d.KH = d.KW = k
+    d.SH = d.SW = d.DH = d.DW = 1
+    d.PH = d.PW = k // 2
+    d.OH, d.OW = H, W
+    d.K, d.N, d.ldo = k * k * C, N, N
+    d.b_mode = lib.B_PACKED
+    d.batch = 1
+    return d
+
+
+def test_plan_selects_the_matrix_core_path_on_the_host():
+    """aldm_igemm_plan (host-only query): a descriptor with a split weight image plans onto the bf16-split kernels,
+    without one (or with the fp32 override / an activation x activation product / a hint) onto the fp32 MFMA; the
+    FLOP count is the algorithmic 2*M*N*K either way."""
+    from audioldm2_amd import lib
+    l = lib.load()
+    d = _conv_desc(lib)
+    bm, bn, sp, kg, mma, fl = _plan(l, lib, d)
+    assert mma == 0 and fl == 2 * (16 * 256 * 16) * 128 * (9 * 128) and (bm, bn) in {(128, 128), (64, 128), (128, 64), (64, 64)}
+    d.w_split = 0x4000
+    assert _plan(l, lib, d)[4] == 1
+    d.hint_mma = 1  # tuned table says: fp32 MFMA for this shape
+    assert _plan(l, lib, d)[4] == 0
+    d.hint_mma = 0
+    prev = l.aldm_igemm_mma(1)  # thread-local override: fp32 MFMA always
+    try:
+        assert _plan(l, lib, d)[4] == 0
+    finally:
+        l.aldm_igemm_mma(prev)
+    assert _plan(l, lib, d)[4] == 1
+    d.b_mode, d.ldb = lib.B_NT, d.K  # activation x activation: no split image can exist
+    assert _plan(l, lib, d)[4] == 0
+    d.b_mode, d.ldb = lib.B_PACKED, 0
+    d.N, d.ldo = 8, 8  # N <= 32 -> the 128x32 tile, which has no bf16-split variant
+    assert _plan(l, lib, d)[:2] == (128, 32) and _plan(l, lib, d)[4] == 0
+
+
+def test_split_image_size_and_forced_tiles():
+    from audioldm2_amd import lib
+    l = lib.load()
+    assert l.aldm_split_bytes(72, 40) == 12 * 3 * 64 * 16  # 4*ceil(72/32) k-octets x 3 parts x Npad x 16 B
+    assert l.aldm_split_bytes(1152, 128) == 144 * 3 * 128 * 16 == 1152 * 128 * 6
+    assert l.aldm_split_bytes(0, 5) == 0
+    d = _conv_desc(lib)
+    d.w_split = 0x4000
+    l.aldm_igemm_force(64, 64, 1, 2)
+    try:
+        assert _plan(l, lib, d)[:5] == (64, 64, 1, 2, 1)
+        l.aldm_igemm_force(256, 128, 1, 1)
+        assert l.aldm_igemm_plan(ctypes.byref(d), None, None, None, None, None, None) != 0
+        with pytest.raises(RuntimeError, match="unsupported forced/hinted tile"):
+            lib.check(1, "plan")
+    finally:
+        l.aldm_igemm_force(0, 0, 0, 0)
+    assert l.aldm_igemm_wave8_mask(5) == 5 and l.aldm_igemm_wave8_mask(-1) in (1, int(os.environ.get("ALDM_IGEMM_W8", "1")))
