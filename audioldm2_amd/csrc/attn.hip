@@ -17,9 +17,38 @@
 
 namespace aldm {
 
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+
+// Exact 3-way split of 8 fp32 values (x = hi + mid + lo, each part the top 16 bits of an fp32) into three bf16x8
+// MFMA operands; element j of an operand is x[j].  Same arithmetic as the igemm engine's A-side split
+// (igemm_kernel.h).
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&part)[3]) {
+    unsigned u[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = x[j];
+        u[0][j] = __builtin_bit_cast(unsigned, v);
+        const float r1 = v - __builtin_bit_cast(float, u[0][j] & 0xFFFF0000u);
+        u[1][j] = __builtin_bit_cast(unsigned, r1);
+        const float r2 = r1 - __builtin_bit_cast(float, u[1][j] & 0xFFFF0000u);
+        u[2][j] = __builtin_bit_cast(unsigned, r2);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(u[q][2 * i + 1], u[q][2 * i], 0x07060302u);
+        part[q] = __builtin_bit_cast(bf16x8, w);
+    }
+}
+
 // QT = 32-query tiles per wave.  With QT = 2 one wave reuses every K / V fragment it loads for 64
 // queries (half the L1/L2 traffic per MFMA); used when the grid still fills the chip.
-template <bool HAS_MASK, int QT>
+// BX: both products on the bf16 matrix cores as 6 partial products of exact operand splits (Q once, K / V / P per
+// key tile, all in registers): 24 MFMAs of 32 cycles per 32x32 tile pair instead of 32 of 64.  The operand layouts
+// carry over unchanged: a 16-wide MFMA k-step takes 8 consecutive entries of what the fp32 kernel feeds one at a time.
+template <bool HAS_MASK, int QT, bool BX = false>
 __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -45,6 +74,19 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) qf[t][4 * g + e] = x[e] * scale;
         }
+    }
+
+    bf16x8 qx[BX ? QT : 1][2][3];  // BX: Q^T operands, k-step s covers d = 16*lh + 8*s .. + 7
+    if constexpr (BX) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float x8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x8[j] = qf[t][8 * s + j];
+                split8(x8, qx[t][s]);
+            }
     }
 
     f32x16 oT[QT];
@@ -88,11 +130,28 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         for (int t = 0; t < QT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+        constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};  // (lo-order products first)
+        if constexpr (BX) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int s = 0; s < 2; ++s) {
+                float x8[8];
 #pragma unroll
-            for (int t = 0; t < QT; ++t)
-                st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kraw[s >> 2][s & 3], qf[t][s], st[t], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
+                bf16x8 kx[3];
+                split8(x8, kx);
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t)
+                        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx[PA_[p]], qx[t][s][PB_[p]], st[t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kraw[s >> 2][s & 3], qf[t][s], st[t], 0, 0, 0);
+        }
 
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -123,11 +182,34 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) oT[t][e] *= alpha;
         }
+        if constexpr (BX) {
+            // k-step s takes the 8 keys of registers r = 8*s .. 8*s + 7 — the same keys in vf (V^T rows) and in st
+            // (P^T columns) of a lane half, so the pairing inside the MFMA is consistent
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+            for (int s = 0; s < 2; ++s) {
+                float x8[8];
 #pragma unroll
-            for (int t = 0; t < QT; ++t)
-                oT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[t][r], oT[t], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
+                bf16x8 vx[3];
+                split8(x8, vx);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x8[j] = st[t][8 * s + j];
+                    bf16x8 px[3];
+                    split8(x8, px);
+#pragma unroll
+                    for (int p = 0; p < 6; ++p)
+                        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vx[PA_[p]], px[PB_[p]], oT[t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    oT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[t][r], oT[t], 0, 0, 0);
+        }
     }
 
 #pragma unroll
@@ -152,6 +234,22 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 
 using namespace aldm;
 
+// matrix-core path of the attention kernel: -1 = default ($ALDM_ATTN_MMA: "bf16x6" or "f32"; f32 until the split
+// kernel has been validated on hardware), 1 = fp32 MFMA, 2 = bf16-split
+static thread_local int g_attn_mma = -1;
+static bool default_attn_bx() {
+    static const bool v = [] {
+        const char* e = getenv("ALDM_ATTN_MMA");
+        return e != nullptr && e[0] == 'b';
+    }();
+    return v;
+}
+extern "C" int aldm_attention_mma(int mode) {
+    const int prev = g_attn_mma;
+    if (mode == -1 || mode == 1 || mode == 2) g_attn_mma = mode;
+    return prev;
+}
+
 extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v, float* out, int B,
                                   int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                                   const float* mask, float scale, void* stream) {
@@ -172,17 +270,24 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
         return e ? atoi(e) : 0;
     }();
     const bool qt2 = env_qt ? env_qt == 2 : (Lk >= 256 && (int64_t)cdiv(Lq, 256) * heads * B >= 512);
+    const bool bx = g_attn_mma < 0 ? default_attn_bx() : g_attn_mma == 2;
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
-#define ALDM_ATTN(M_, Q_)                                                                                \
-    hipLaunchKernelGGL((attention_d32_kernel<M_, Q_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
+#define ALDM_ATTN(M_, Q_, X_)                                                                                 \
+    hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
                        ldk, ldv, ldo, mask, scale)
+#define ALDM_ATTN_X(M_, Q_)          \
+    do {                             \
+        if (bx) ALDM_ATTN(M_, Q_, true); \
+        else ALDM_ATTN(M_, Q_, false);   \
+    } while (0)
     if (mask) {
-        if (qt2) ALDM_ATTN(true, 2);
-        else ALDM_ATTN(true, 1);
+        if (qt2) ALDM_ATTN_X(true, 2);
+        else ALDM_ATTN_X(true, 1);
     } else {
-        if (qt2) ALDM_ATTN(false, 2);
-        else ALDM_ATTN(false, 1);
+        if (qt2) ALDM_ATTN_X(false, 2);
+        else ALDM_ATTN_X(false, 1);
     }
+#undef ALDM_ATTN_X
 #undef ALDM_ATTN
     ALDM_LAUNCH_CHECK("aldm_attention_d32");
     return 0;

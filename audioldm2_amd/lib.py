@@ -71,6 +71,7 @@ _SIGS = {
     "aldm_gn_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_void_p]),
+    "aldm_attention_mma": (C.c_int, [C.c_int]),
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_float, C.c_void_p]),

@@ -203,6 +203,12 @@ def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0) -> 
     _l.load().aldm_igemm_force(bm, bn, splits, kgroups)
 
 
+def attention_mma(mode: int) -> int:
+    """Matrix-core path of ops.attention (aldm_attention_mma): 1 fp32 MFMA, 2 bf16-split, -1 default.  Returns the
+    previous mode."""
+    return _l.load().aldm_attention_mma(mode)
+
+
 def igemm_mma(mode: int) -> int:
     """Tuning override for tools/tests (aldm_igemm_mma): 0 automatic, 1 fp32 MFMA always, 2 bf16-split wherever an
     instantiation exists.  Returns the previous mode."""

@@ -193,6 +193,10 @@ int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
 int aldm_attention_d32(const float* q, const float* k, const float* v, float* out,
                        int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                        const float* mask, float scale, void* stream);
+/* Matrix-core path of aldm_attention_d32 on this thread: 1 = fp32 MFMA, 2 = bf16-split (both products as 6 bf16 partial
+ * products of exact operand splits, like the igemm engine), -1 = default ($ALDM_ATTN_MMA, "f32" unless it says
+ * "bf16x6").  Returns the previous mode.                                                                        */
+int aldm_attention_mma(int mode);
 /* row softmax with pre-scale: y = softmax(scale * x) over the last dim of [M, N]
  * (model.py:220-221)                                                                        */
 int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale, void* stream);

@@ -459,9 +459,14 @@ def test_attention_d32(ops, B, heads, Lq, Lk, masked):
             mask[1, 0] = 1
     ref = ref_attention(q.contiguous(), k.contiguous(), v.contiguous(), heads, mask)
     qd, kvd = qb.cuda(), kvb.cuda()
-    y = ops.attention(qd[:, :, :Cc], kvd[:, :, :Cc], kvd[:, :, Cc:], heads,
-                      mask=None if mask is None else mask.cuda())
-    assert rel_err(y, ref) < GEMM_TOL
+    for mode in (1, 2):  # fp32 MFMA, bf16-split
+        prev = ops.attention_mma(mode)
+        try:
+            y = ops.attention(qd[:, :, :Cc], kvd[:, :, :Cc], kvd[:, :, Cc:], heads,
+                              mask=None if mask is None else mask.cuda())
+        finally:
+            ops.attention_mma(prev)
+        assert rel_err(y, ref) < GEMM_TOL, f"attention mma mode {mode}"
 
 
 def test_attention_online_softmax_rescale(ops):
