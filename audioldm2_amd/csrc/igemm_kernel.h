@@ -1,4 +1,7 @@
-// igemm_kernel.h — the implicit-GEMM convolution / GEMM kernel on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// igemm_kernel.h — the implicit-GEMM convolution / GEMM kernel, on the fp32 MFMA (v_mfma_f32_32x32x2_f32) or,
+// with BX = true, on the bf16 matrix cores with every fp32 product evaluated as six bf16 partial products of
+// exact 3-way operand splits (v_mfma_f32_32x32x16_bf16, "BF16x6"; the default path — see the notes at Frag /
+// the BX branch of the K loop below and DESIGN.md §3.1b).
 //
 //   out[m, n] = epi( sum_k A[m, k] * W[k, n] ),  m = (b, oh, ow), k = (kh, kw, ci)
 //
@@ -23,6 +26,8 @@
 //  * epilogue fusion: bias, timestep-embedding row bias, activation, residual, scale, accumulate,
 //    strided row remap (polyphase transposed conv);
 //  * blockIdx is remapped so each XCD (private 4 MiB L2) walks a contiguous range of tiles.
+// The bullets on the LDS image and the software pipeline describe the fp32-MFMA instantiations; the BX ones keep
+// gather, prologues, epilogues and split-K but use a 12-slot bf16 image and a deeper pipeline (below).
 #pragma once
 #include "common.h"
 #include <type_traits>
@@ -95,7 +100,8 @@ constexpr int igemm_waves_per_simd(int BM, int BN, int waves, bool BX) {
 // Measured and rejected (profiles/r01_igemm_pipeline_variants_ab.txt, r01_igemm_two_load_stages_ab.txt):
 // folding commit() into the second half's MFMAs with sched_barrier fences, and a second register stage
 // of global loads (first for the 64x64 tile, later for every tile) — all within +-2 % of this simpler
-// pipeline on the UNet's shapes: neither load latency nor prologue VALU is what limits it.
+// pipeline on the UNet's shapes: neither load latency nor prologue VALU is what limits the fp32-MFMA kernels
+// (their 64-cycle MFMAs hide both).  The bf16-split kernels are the opposite case and use both ideas.
 //
 // KGRP = wave groups per block.  KGRP = 2 (512 threads): two 4-wave groups work on the SAME output tile,
 // each with its own LDS double buffer, group g taking k-tiles g, g+2, ...; their accumulators are added
