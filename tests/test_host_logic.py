@@ -169,3 +169,27 @@ def test_packed_weight_split_image_is_lazy_and_mode_gated(monkeypatch):
             ops.set_mma("bf16")
     finally:
         ops.set_mma(prev)
+
+
+def test_bench_contract_defaults_and_no_cpu_path():
+    """bench.py: flag defaults are the BASELINE configuration (N = 1, batch 8, 200 DDIM steps, a K/W that finishes in
+    minutes), the roofline peaks are the guide's numbers, and without a GPU it refuses to run (no CPU fallback)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    old = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.ddim_steps, a.model, a.mma) == (1, 2, 1, 8, 200, "audioldm2-full", None)
+    assert bench.PEAK_F32_MFMA_TFLOPS == 157.3 and bench.PEAK_BF16X6_TFLOPS == 416.7
+    assert set(bench.UNET_GFLOP_PER_FWD_SAMPLE) == {"audioldm2-full", "audioldm2-full-large-1150k",
+                                                    "audioldm2-speech-gigaspeech", "audioldm_48k"}
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "needs the MI355X" in r.stderr and not r.stdout.strip()
