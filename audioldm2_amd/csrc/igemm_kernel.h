@@ -49,6 +49,11 @@ enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GEN
 #ifndef ALDM_BX_INTERLEAVE
 #define ALDM_BX_INTERLEAVE 1
 #endif
+// Experimental (not validated on hardware yet, compiled out): the pre-split B operand of the bf16-split kernels
+// goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write), one k-tile ahead.
+#ifndef ALDM_BX_GLDS
+#define ALDM_BX_GLDS 0
+#endif
 #ifndef ALDM_ABLATE
 #define ALDM_ABLATE 0  // debug builds only (tools/gpu/build_ablate.sh): drop pieces of the BX K loop to time the rest
 #endif
@@ -281,9 +286,10 @@ void igemm_kernel(const IgemmK p) {
         b_kidx[pp] = (kt0 + grp) * b_ks + pp * b_kps + b_k0;
     }
 
+    constexpr bool GLDS = BX && ALDM_BX_GLDS != 0;
     // one in-flight k-tile of this thread's global loads
     struct Stage {
-        f32x4 ra[PA], rb[PB];
+        f32x4 ra[PA], rb[GLDS ? 1 : PB];
         f32x4 rsc[(AFF && !UNI) ? PA : 1], rsh[(AFF && !UNI) ? PA : 1];
         unsigned avalid, bvalid;
     };
@@ -303,13 +309,15 @@ void igemm_kernel(const IgemmK p) {
             }
         }
         r.bvalid = 0;
+        if constexpr (!GLDS) {
 #pragma unroll
-        for (int pp = 0; pp < PB; ++pp) {
-            const bool ok = b_kidx[pp] < b_klim && pp * b_nps + b_n0 < b_nlim;
-            r.rb[pp] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[pp] : wgt);
-            r.bvalid |= (ok ? 1u : 0u) << pp;
-            b_ptr[pp] += b_kt * KGRP;
-            b_kidx[pp] += b_ks * KGRP;
+            for (int pp = 0; pp < PB; ++pp) {
+                const bool ok = b_kidx[pp] < b_klim && pp * b_nps + b_n0 < b_nlim;
+                r.rb[pp] = *reinterpret_cast<const f32x4*>(ok ? b_ptr[pp] : wgt);
+                r.bvalid |= (ok ? 1u : 0u) << pp;
+                b_ptr[pp] += b_kt * KGRP;
+                b_kidx[pp] += b_ks * KGRP;
+            }
         }
         // advance A to this group's next k-tile
         t_ci += KSTEP;
@@ -400,6 +408,23 @@ void igemm_kernel(const IgemmK p) {
 #endif
         Bs[buf][b_skg + pp * b_skgs][b_sc + pp * b_scs] = v;
     };
+    // GLDS: the next B k-tile of this wave group, global -> LDS.  A wave's 64 lanes cover 64 consecutive columns of
+    // one 16-byte slot row, i.e. 1 KB contiguous in LDS = what one global_load_lds_dwordx4 writes (M0 = the wave's
+    // slot base, lane i lands at +16*i).  Columns past Npad read a valid dummy address; they only feed output
+    // columns >= N, which are never stored.
+    auto dma_b = [&](int buf) {
+        if constexpr (GLDS) {
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                const bool ok = b_n0 < b_nlim;
+                const int slot = __builtin_amdgcn_readfirstlane(b_skg + pp * b_skgs);
+                const int col0 = __builtin_amdgcn_readfirstlane(b_sc & ~63);
+                __builtin_amdgcn_global_load_lds(ok ? b_ptr[pp] : wgt,
+                                                 (__attribute__((address_space(3))) void*)&Bs[buf][slot][col0], 16, 0, 0);
+                b_ptr[pp] += b_kt * KGRP;
+            }
+        }
+    };
     auto commit = [&](Stage& r, int buf) {
 #pragma unroll
         for (int pp = 0; pp < PA; ++pp) {
@@ -409,8 +434,10 @@ void igemm_kernel(const IgemmK p) {
             }
             store_a(r, buf, pp);
         }
+        if constexpr (!GLDS) {
 #pragma unroll
-        for (int pp = 0; pp < PB; ++pp) store_b(r, buf, pp);
+            for (int pp = 0; pp < PB; ++pp) store_b(r, buf, pp);
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -530,6 +557,7 @@ void igemm_kernel(const IgemmK p) {
             // newest loads and drain the whole queue (vmcnt(0)), i.e. no prefetch at all.
             Stage r0, r1;
             Frag f0, f1;
+            if (tile_of(0) < kt1) dma_b(0);
             if (tile_of(0) < kt1) issue_loads(r0);
             if (tile_of(1) < kt1) issue_loads(r1);
             if (tile_of(0) < kt1) commit(r0, 0);
@@ -539,6 +567,7 @@ void igemm_kernel(const IgemmK p) {
                 constexpr bool ST = decltype(steady)::value;
                 const bool cur = ST || tile_of(it) < kt1, nxt = ST || tile_of(it + 1) < kt1;
                 const bool nx2 = ST || tile_of(it + 2) < kt1;
+                if (nxt) dma_b(buf ^ 1);  // (GLDS only) B of tile it+1: `buf ^ 1` is free since the last barrier
                 if (nx2) issue_loads(ld);
                 __builtin_amdgcn_sched_barrier(0);
                 if (cur) read_frags(f1, buf, 1);
