@@ -245,6 +245,28 @@ def gen_e2e_48k(steps: int, B: int, name: str):
          wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(np.sqrt((wav.astype(np.float64) ** 2).mean())))
 
 
+def gen_e2e_named(model_name: str, steps: int, B: int, name: str, keys_json: str):
+    """BASELINE configs 4 / 5: reference generate_batch of `audioldm2-full-large-1150k` (three context slots,
+    transformer depth 2; utils.py:118-120) or `audioldm2-speech-gigaspeech` (one 512-token AudioMAE context,
+    utils.py:121-187), 16 kHz VAE + vocoder.  Waveform stored like the 48 kHz fixture (head + every 16th sample)."""
+    ld = _ref_latent_diffusion_named(model_name, keys_json)
+    ld.latent_t_size = 256
+    rec = {}
+    orig_decode = ld.decode_first_stage
+
+    def decode_hook(z):
+        rec["latent"] = z.clone()
+        return orig_decode(z)
+    ld.decode_first_stage = decode_hook
+    _seed_all()
+    t0 = time.time()
+    wav = ld.generate_batch(cases.e2e_batch(B), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
+    print(f"{name}: reference generate_batch({model_name}) B={B} steps={steps}: {time.time()-t0:.1f}s wave {wav.shape} "
+          f"rms {np.sqrt((wav**2).mean()):.4f} latent std {rec['latent'].std():.3f}")
+    save(name, latent=rec["latent"], wave_head=wav[..., :32768], wave_dec=wav[..., ::16],
+         wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(np.sqrt((wav.astype(np.float64) ** 2).mean())))
+
+
 def _seed_all():
     import random
     random.seed(cases.E2E_SEED)
@@ -320,5 +342,9 @@ if __name__ == "__main__":
         gen_e2e_48k(2, 1, "e2e_48k_2step_b1")
     if "all" in what or "ancestral" in what:
         gen_ancestral(4, 1, "ancestral_4step_b1")
+    if "all" in what or "e2espeech" in what:
+        gen_e2e_named("audioldm2-speech-gigaspeech", 2, 1, "e2e_speech_2step_b1", "e2espeech_statedict_keys.json")
+    if "all" in what or "e2elarge" in what:
+        gen_e2e_named("audioldm2-full-large-1150k", 2, 1, "e2e_large_2step_b1", "e2elarge_statedict_keys.json")
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")

@@ -26,7 +26,9 @@ _GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def hot_path_shapes(model_name: str = "audioldm2-full") -> Dict[str, tuple]:
     """Names/shapes of the reference's hot-path tensors (recorded from the real LatentDiffusion)."""
-    fname = {"audioldm2-full": "e2e_statedict_keys.json", "audioldm_48k": "e2e48k_statedict_keys.json"}[model_name]
+    fname = {"audioldm2-full": "e2e_statedict_keys.json", "audioldm_48k": "e2e48k_statedict_keys.json",
+             "audioldm2-speech-gigaspeech": "e2espeech_statedict_keys.json",
+             "audioldm2-full-large-1150k": "e2elarge_statedict_keys.json"}[model_name]
     with open(os.path.join(_GOLD, fname)) as f:
         return {k: tuple(v) for k, v in json.load(f).items()}
 
@@ -40,6 +42,17 @@ def oracle_48k(seed: int = 0) -> "OracleLatentDiffusion":
                               cond_cfg=default_audioldm_config("audioldm_48k")["model"]["params"]["cond_stage_config"])
     o.channels, o.latent_t_size, o.latent_f_size = 16, 128, 32
     return o
+
+
+def oracle_named(model_name: str, seed: int = 0) -> "OracleLatentDiffusion":
+    """BASELINE configs 4 / 5: `audioldm2-full-large-1150k` (context_dim [768, 1024, None], transformer depth 2,
+    utils.py:118-120) and `audioldm2-speech-gigaspeech` (one 512-token context, utils.py:121-187); 16 kHz VAE and
+    vocoder as in the full model.  The UNet config is the reference's (audioldm2_amd.pipeline.default_audioldm_config
+    reproduces utils.py's dicts and is checked against them in tests/test_host_logic.py)."""
+    from audioldm2_amd.pipeline import default_audioldm_config
+    params = default_audioldm_config(model_name)["model"]["params"]
+    return OracleLatentDiffusion(sd=weights.make_state_dict(hot_path_shapes(model_name), seed=seed),
+                                 unet_cfg=params["unet_config"]["params"], cond_cfg=params["cond_stage_config"])
 
 
 class OracleLatentDiffusion:

@@ -59,6 +59,21 @@ def test_latent_diffusion_hot_path_keys_and_reference_checkpoint_loading():
         ld.load_reference_state_dict(sd)
 
 
+@pytest.mark.parametrize("model_name,keys_json", [("audioldm_48k", "e2e48k_statedict_keys.json"),
+                                                  ("audioldm2-speech-gigaspeech", "e2espeech_statedict_keys.json"),
+                                                  ("audioldm2-full-large-1150k", "e2elarge_statedict_keys.json")])
+def test_other_configs_hot_path_keys_match_the_reference(model_name, keys_json):
+    """BASELINE configs 3-5: the hot-path tensors of build_model(name) are exactly the real reference's
+    (names and shapes recorded by oracle/make_golden.py from the reference's LatentDiffusion)."""
+    from audioldm2_amd.pipeline import build_model
+    m = build_model(model_name=model_name)
+    ours = {k: tuple(v.shape) for k, v in m.state_dict().items()
+            if k.startswith("model.diffusion_model.") or k.startswith("first_stage_model.")}
+    with open(os.path.join(GOLD, keys_json)) as f:
+        ref = {k: tuple(v) for k, v in json.load(f).items()}
+    assert ours == ref
+
+
 def test_ddim_sampler_tables_match_reference_exactly():
     from audioldm2_amd.ddim import DDIMSampler
     from audioldm2_amd.pipeline import build_model

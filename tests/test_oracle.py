@@ -163,3 +163,19 @@ def test_e2e_oracle_matches_reference_generate_batch_48k():
     assert rel(out["latent"], g["latent"]) < 1e-4
     assert rel(out["wave"][..., :32768], g["wave_head"]) < 1e-4
     assert rel(out["wave"][..., ::16], g["wave_dec"]) < 1e-4
+
+
+@pytest.mark.parametrize("model_name,fixture", [("audioldm2-speech-gigaspeech", "e2e_speech_2step_b1"),
+                                                ("audioldm2-full-large-1150k", "e2e_large_2step_b1")])
+def test_e2e_oracle_matches_reference_generate_batch_speech_and_large(model_name, fixture):
+    """BASELINE configs 4 / 5 vs the real reference's generate_batch fixtures (B=1, 2 DDIM steps, CFG 3.5): one
+    512-token context (speech) and three context slots with transformer depth 2 (large)."""
+    from oracle.pipeline import oracle_named
+    g = gold(fixture)
+    o = oracle_named(model_name)
+    torch.manual_seed(cases.E2E_SEED)
+    out = o.generate_batch(cases.e2e_batch(1), unconditional_guidance_scale=3.5, ddim_steps=2)
+    assert out["wave"].shape[-1] == int(g["wave_len"])
+    assert rel(out["latent"], g["latent"]) < 1e-4
+    assert rel(out["wave"][..., :32768], g["wave_head"]) < 1e-4
+    assert rel(out["wave"][..., ::16], g["wave_dec"]) < 1e-4
