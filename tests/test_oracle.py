@@ -179,3 +179,17 @@ def test_e2e_oracle_matches_reference_generate_batch_speech_and_large(model_name
     assert rel(out["latent"], g["latent"]) < 1e-4
     assert rel(out["wave"][..., :32768], g["wave_head"]) < 1e-4
     assert rel(out["wave"][..., ::16], g["wave_dec"]) < 1e-4
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", [(16000, 1024, 64, 0, 8000), (48000, 2048, 256, 20, 24000)])
+def test_mel_filterbank_agrees_with_an_independent_slaney_implementation(sr, n_fft, n_mels, fmin, fmax):
+    """librosa==0.9.2 (the reference's mel basis, stft.py:145-147) is not installed, so oracle/stft.py restates the
+    published Slaney definition; transformers.audio_utils.mel_filter_bank is a second, independent restatement of the
+    same definition (norm="slaney", mel_scale="slaney") and must give the same basis for both shipped STFT configs."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import stft as ost
+    ours = np.asarray(ost.mel_filterbank(sr, n_fft, n_mels, fmin, fmax), dtype=np.float64)
+    theirs = au.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=fmin,
+                                max_frequency=fmax, sampling_rate=sr, norm="slaney", mel_scale="slaney").T
+    assert ours.shape == theirs.shape == (n_mels, n_fft // 2 + 1)
+    assert np.abs(ours - theirs).max() < 1e-7 * np.abs(theirs).max() + 1e-9
