@@ -18,5 +18,8 @@ How it is pinned (the reference ships no tests, no golden vectors — SURVEY.md 
     against the live reference classes when /root/reference is present.
   * third-party arithmetic not vendored by the reference: `librosa==0.9.2` mel filterbank /
     pad_center (stft.py:5-6,42,145-147) is restated from its published definition in
-    `oracle/stft.py` — parity unpinned for that piece (no librosa offline, no reference test).
+    `oracle/stft.py` — parity unpinned for that piece (no librosa offline, no reference test); the restated basis is
+    cross-checked against transformers.audio_utils.mel_filter_bank, an independent restatement of the same definition.
+  * `oracle/bf16x6.py` is not a restatement of the reference but of how the HIP igemm kernels evaluate fp32 products
+    on the bf16 matrix cores (exact operand split, six partial products) and of the split weight image's layout.
 """
