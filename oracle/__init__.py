@@ -20,6 +20,10 @@ How it is pinned (the reference ships no tests, no golden vectors — SURVEY.md 
     pad_center (stft.py:5-6,42,145-147) is restated from its published definition in
     `oracle/stft.py` — parity unpinned for that piece (no librosa offline, no reference test); the restated basis is
     cross-checked against transformers.audio_utils.mel_filter_bank, an independent restatement of the same definition.
+  * `oracle/seqgen.py` (the AudioMAE-token sequence generator): restates sequence_input.py and the
+    un-vendored `transformers==4.30.2` GPT2Model it drives; pinned by fixtures from the REAL reference class running on
+    the installed transformers (5.x — same GPT-2 arithmetic), `GPT2Config.from_pretrained("gpt2")` replaced by the
+    identical default GPT2Config() because the Hub is unreachable.
   * `oracle/bf16x6.py` is not a restatement of the reference but of how the HIP igemm kernels evaluate fp32 products
     on the bf16 matrix cores (exact operand split, six partial products) and of the split weight image's layout.
 """

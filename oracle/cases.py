@@ -127,3 +127,19 @@ def e2e_batch_48k(B: int):
     b["log_mel_spec"] = torch.zeros((B, 1024, 256))
     b["fbank"] = b["log_mel_spec"]
     return b
+
+
+# ---- §8(f) rank 1: AudioMAE-token sequence generator (sequence_input.py) -------------------------------------------
+SEQGEN_FULL = dict(keys=["film_clap_cond1", "crossattn_flan_t5"], dims=[512, 1024], steps=8)        # utils.py:351-368
+SEQGEN_SPEECH = dict(keys=["film_clap_cond1", "crossattn_vits_phoneme"], dims=[512, 192], steps=24)  # utils.py:124-143 (512 steps there)
+
+
+def seqgen_cond(cfg: dict, B: int, T: int, seed: int = 5) -> dict:
+    """Synthetic conditioning for the generator: a CLAP-like [B, 1, 512] vector (tensor-valued, all-ones mask) and a
+    [B, T, D] sequence whose last quarter is padding (mask 0) for every odd sample."""
+    g = torch.Generator().manual_seed(seed)
+    film = torch.randn(B, 1, cfg["dims"][0], generator=g)
+    seq = torch.randn(B, T, cfg["dims"][1], generator=g)
+    mask = torch.ones(B, T)
+    mask[1::2, T - T // 4:] = 0
+    return {cfg["keys"][0]: film, cfg["keys"][1]: [seq, mask]}

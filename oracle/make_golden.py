@@ -267,6 +267,25 @@ def gen_e2e_named(model_name: str, steps: int, B: int, name: str, keys_json: str
          wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(np.sqrt((wav.astype(np.float64) ** 2).mean())))
 
 
+def gen_seqgen():
+    """§8(f) rank 1: the REAL Sequence2AudioMAE.generate (sequence_input.py:294-325; transformers GPT2Model underneath) for
+    the full model's generator configuration (8 tokens from CLAP + T5) and the speech model's (CLAP + phonemes; 24 of
+    its 512 steps), deterministic weights, padded conditioning."""
+    keys = None
+    for name, cfg, B, T in (("seqgen_full_8step_b2", cases.SEQGEN_FULL, 2, 20), ("seqgen_speech_24step_b2", cases.SEQGEN_SPEECH, 2, 40)):
+        m = refimport.sequence_generator(cfg["steps"], cfg["keys"], cfg["dims"])
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if k != "model.wte.weight"}  # token table: unused
+        sd = weights.make_state_dict(shapes, seed=0)
+        assert m.load_state_dict(sd, strict=False).missing_keys == ["model.wte.weight"]
+        cond = cases.seqgen_cond(cfg, B, T)
+        t0 = time.time()
+        out, _ = m.generate(None, cond_dict=cond)
+        print(f"{name}: reference generate steps={cfg['steps']} B={B}: {time.time()-t0:.1f}s out {tuple(out.shape)} std {out.std():.3f}")
+        save(name, out=out)
+        with open(os.path.join(OUT, name + "_keys.json"), "w") as f:
+            json.dump({k: list(v) for k, v in shapes.items()}, f)
+
+
 def _seed_all():
     import random
     random.seed(cases.E2E_SEED)
@@ -346,5 +365,7 @@ if __name__ == "__main__":
         gen_e2e_named("audioldm2-speech-gigaspeech", 2, 1, "e2e_speech_2step_b1", "e2espeech_statedict_keys.json")
     if "all" in what or "e2elarge" in what:
         gen_e2e_named("audioldm2-full-large-1150k", 2, 1, "e2e_large_2step_b1", "e2elarge_statedict_keys.json")
+    if "all" in what or "seqgen" in what:
+        gen_seqgen()
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")

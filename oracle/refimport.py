@@ -17,7 +17,7 @@ from unittest.mock import MagicMock
 REF_ROOT = os.environ.get("ALDM_REFERENCE_ROOT", "/root/reference")
 _STUB_ROOTS = {"soundfile", "progressbar", "librosa", "torchaudio", "torchvision", "timm", "torchlibrosa",
                "phonemizer", "unidecode", "ftfy", "chardet", "gradio", "ipdb", "pytorch_lightning",
-               "taming", "kornia", "wandb", "matplotlib"}
+               "taming", "kornia", "wandb", "matplotlib", "soxr"}
 
 
 class _StubLoader(importlib.abc.Loader):
@@ -109,3 +109,18 @@ def ddim_sampler_cls():
     install()
     from audioldm2.latent_diffusion.models.ddim import DDIMSampler
     return DDIMSampler
+
+
+def sequence_generator(sequence_gen_length: int, sequence_input_key, sequence_input_embed_dim):
+    """The real `Sequence2AudioMAE` (audioldm2/audiomae_gen/sequence_input.py) without conditioner sub-modules (the hot
+    function `generate` takes an explicit cond_dict).  `GPT2Config.from_pretrained("gpt2")` (sequence_input.py:69) needs
+    the Hub; GPT2Config()'s defaults ARE that configuration (768 / 12 layers / 12 heads / 1024 positions / gelu_new),
+    so it is patched to return them."""
+    install()
+    from transformers import GPT2Config
+    GPT2Config.from_pretrained = classmethod(lambda cls, name, *a, **k: GPT2Config())
+    from audioldm2.audiomae_gen.sequence_input import Sequence2AudioMAE
+    return Sequence2AudioMAE(base_learning_rate=2e-4, sequence_gen_length=sequence_gen_length,
+                             sequence_input_key=list(sequence_input_key),
+                             sequence_input_embed_dim=list(sequence_input_embed_dim), cond_stage_config={},
+                             batchsize=16).eval()

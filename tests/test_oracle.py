@@ -3,6 +3,7 @@ produced by running the REAL reference classes (tests/golden/*.npz).  This is wh
 Tolerance: the oracle performs the same ATen ops in the same order, so agreement is at fp32
 round-off of thread-count-dependent reductions: max|err| <= 2e-5 * max|ref| (usually exactly 0).
 """
+import json
 import os
 
 import numpy as np
@@ -193,3 +194,35 @@ def test_mel_filterbank_agrees_with_an_independent_slaney_implementation(sr, n_f
                                 max_frequency=fmax, sampling_rate=sr, norm="slaney", mel_scale="slaney").T
     assert ours.shape == theirs.shape == (n_mels, n_fft // 2 + 1)
     assert np.abs(ours - theirs).max() < 1e-7 * np.abs(theirs).max() + 1e-9
+
+
+# ---- §8(f) rank 1: the AudioMAE-token sequence generator (GPT-2 autoregressive loop) --------------------------------
+def _seqgen_sd(fixture):
+    with open(os.path.join(GOLD, fixture + "_keys.json")) as f:
+        return weights.make_state_dict({k: tuple(v) for k, v in json.load(f).items()}, seed=0)
+
+
+@pytest.mark.parametrize("fixture,cfg,T", [("seqgen_full_8step_b2", cases.SEQGEN_FULL, 20),
+                                           ("seqgen_speech_24step_b2", cases.SEQGEN_SPEECH, 40)])
+def test_sequence_generator_oracle_matches_reference_generate(fixture, cfg, T):
+    """oracle/seqgen.py vs the REAL Sequence2AudioMAE.generate (sequence_input.py:294-325, transformers GPT2Model) on the
+    committed fixture: the reference's full re-forward order and the key/value-cached order both reproduce it."""
+    from oracle import seqgen
+    sd = _seqgen_sd(fixture)
+    want = torch.from_numpy(gold(fixture)["out"])
+    x, mask = seqgen.input_sequence_and_mask(sd, cases.seqgen_cond(cfg, 2, T), cfg["keys"], cfg["steps"])
+    assert x.shape[1] == T + 2 + 1 + 2  # [sos, clap, eos] + [sos, T tokens, eos]
+    assert rel(seqgen.generate_full(sd, x, mask, cfg["steps"]), want) < 1e-5
+    assert rel(seqgen.generate_cached(sd, x, mask, cfg["steps"]), want) < 1e-5
+
+
+def test_sequence_generator_cached_decode_equals_full_reforward_over_many_steps():
+    """The size-independent property an accelerated decode rests on: with a causal model the cached evaluation order
+    is the same function as the reference's O(n^2) re-forward loop, here over 96 generated positions."""
+    from oracle import seqgen
+    sd = _seqgen_sd("seqgen_speech_24step_b2")
+    cfg = cases.SEQGEN_SPEECH
+    x, mask = seqgen.input_sequence_and_mask(sd, cases.seqgen_cond(cfg, 1, 12, seed=9), cfg["keys"], 96)
+    a = seqgen.generate_full(sd, x, mask, 96)
+    b = seqgen.generate_cached(sd, x, mask, 96)
+    assert a.shape == (1, 96, 768) and rel(b, a) < 1e-5

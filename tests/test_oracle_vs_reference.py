@@ -73,3 +73,20 @@ def test_audio_front_end_helpers_equal_live_reference():
     fb = torch.randn(1000, 65)
     for tl in (1024, 900):
         assert torch.equal(P._pad_spec(fb, tl), rt._pad_spec(fb, tl))
+
+
+def test_sequence_generator_oracle_equals_live_reference():
+    """§8(f) rank 1: Sequence2AudioMAE.generate (sequence_input.py:294-325) on conditioning that is not in the committed
+    fixtures (other batch, lengths, seed), full re-forward and key/value-cached restatements."""
+    from oracle import seqgen
+    cfg = dict(cases.SEQGEN_FULL, steps=5)
+    m = refimport.sequence_generator(cfg["steps"], cfg["keys"], cfg["dims"])
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if k != "model.wte.weight"}
+    sd = weights.make_state_dict(shapes, seed=3)
+    m.load_state_dict(sd, strict=False)
+    cond = cases.seqgen_cond(cfg, 3, 9, seed=21)
+    with torch.no_grad():
+        want, _ = m.generate(None, cond_dict=cond)
+    x, mask = seqgen.input_sequence_and_mask(sd, cond, cfg["keys"], cfg["steps"])
+    assert rel(seqgen.generate_full(sd, x, mask, cfg["steps"]), want) < 1e-5
+    assert rel(seqgen.generate_cached(sd, x, mask, cfg["steps"]), want) < 1e-5
