@@ -37,6 +37,8 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
         case ALDM_ACT_TANH: return tanhf(v);
         case ALDM_ACT_LOGCLAMP: return logf(fmaxf(v, slope));
         case ALDM_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case ALDM_ACT_GELU_TANH:  // transformers NewGELUActivation (GPT-2 "gelu_new")
+            return 0.5f * v * (1.0f + tanhf(0.79788456080286535588f * (v + 0.044715f * v * v * v)));
         default: return v;
     }
 }

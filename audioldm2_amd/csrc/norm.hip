@@ -252,9 +252,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---- row softmax (VAE mid attention, 4096-wide rows): one block per row, row staged in LDS ----
+// MASKED (GPT-2 style attention rows of the sequence generator): row r = (b * heads + h) * q_rows + i; key j takes part
+// iff keymask[b, j] != 0 and j <= q_pos0 + i (causal); excluded keys get weight exactly 0 (the reference adds finfo.min
+// to them, transformers GPT2Attention: same result whenever a row keeps at least one key, which the always-unmasked
+// start token guarantees).
+template <bool MASKED>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
                                                            float* __restrict__ y, int N,
-                                                           float scale) {
+                                                           float scale, const float* __restrict__ keymask,
+                                                           int rows_per_batch, int q_rows, int q_pos0) {
     extern __shared__ __attribute__((aligned(16))) float srow[];
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
@@ -262,8 +268,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float* yr = y + row * N;
     const int tid = threadIdx.x;
     float mx = -INFINITY;
+    const float* km = nullptr;
+    int jmax = N;
+    if (MASKED) {
+        km = keymask + (row / rows_per_batch) * N;
+        jmax = q_pos0 + (int)(row % q_rows) + 1;  // keys [0, jmax) are causally visible
+    }
     for (int i = tid; i < N; i += 256) {
-        const float v = xr[i] * scale;
+        float v = xr[i] * scale;
+        if (MASKED && (i >= jmax || km[i] == 0.0f)) v = -INFINITY;
         srow[i] = v;
         mx = fmaxf(mx, v);
     }
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     __syncthreads();
     float s = 0.f;
     for (int i = tid; i < N; i += 256) {
-        const float e = expf(srow[i] - mx);
+        const float e = (MASKED && srow[i] == -INFINITY) ? 0.0f : expf(srow[i] - mx);
         srow[i] = e;
         s += e;
     }
@@ -355,8 +368,21 @@ extern "C" int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, flo
     ALDM_CHECK(x && y && M > 0 && N > 0, "aldm_softmax_rows: bad args");
     ALDM_CHECK((int64_t)N * 4 <= 60 * 1024, "aldm_softmax_rows: row of %d floats exceeds the 60 KiB LDS stage", N);
     ALDM_CHECK(M < (1ll << 31), "aldm_softmax_rows: too many rows");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), (size_t)N * 4,
-                       (hipStream_t)stream, x, y, N, scale);
+    hipLaunchKernelGGL(softmax_rows_kernel<false>, dim3((unsigned)M), dim3(256), (size_t)N * 4,
+                       (hipStream_t)stream, x, y, N, scale, nullptr, 1, 1, 0);
     ALDM_LAUNCH_CHECK("aldm_softmax_rows");
+    return 0;
+}
+
+extern "C" int aldm_softmax_rows_masked(const float* x, float* y, int B, int heads, int q_rows, int N, float scale,
+                                        const float* keymask, int q_pos0, void* stream) {
+    ALDM_CHECK(x && y && keymask && B > 0 && heads > 0 && q_rows > 0 && N > 0 && q_pos0 >= 0,
+               "aldm_softmax_rows_masked: bad args");
+    ALDM_CHECK((int64_t)N * 4 <= 60 * 1024, "aldm_softmax_rows_masked: row of %d floats exceeds the 60 KiB LDS stage", N);
+    const int64_t M = (int64_t)B * heads * q_rows;
+    ALDM_CHECK(M < (1ll << 31), "aldm_softmax_rows_masked: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3((unsigned)M), dim3(256), (size_t)N * 4, (hipStream_t)stream, x, y,
+                       N, scale, keymask, heads * q_rows, q_rows, q_pos0);
+    ALDM_LAUNCH_CHECK("aldm_softmax_rows_masked");
     return 0;
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALDM_LIB_PATH") or os.path.join(_HERE, "libaldm_hip.so")  # override: debug builds
 ABI_VERSION = 4
 
-ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU = range(6)
+ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU, ACT_GELU_TANH = range(7)
 B_PACKED, B_NT = 0, 1
 EPI_PLAIN, EPI_GEGLU = 0, 1
 
@@ -75,6 +75,8 @@ _SIGS = {
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_float, C.c_void_p]),
+    "aldm_softmax_rows_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
                                     C.c_void_p]),
     "aldm_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

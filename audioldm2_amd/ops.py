@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import lib as _l
-from .lib import (ACT_GELU, ACT_LOGCLAMP, ACT_LRELU, ACT_NONE, ACT_SILU, ACT_TANH, B_NT, B_PACKED,
+from .lib import (ACT_GELU, ACT_GELU_TANH, ACT_LOGCLAMP, ACT_LRELU, ACT_NONE, ACT_SILU, ACT_TANH, B_NT, B_PACKED,
                   IgemmDesc)
 
 
@@ -495,6 +495,19 @@ def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     y = torch.empty_like(x)
     _l.check(_l.load().aldm_softmax_rows(x.data_ptr(), y.data_ptr(), x.numel() // N, N, scale,
                                          _stream()), "softmax_rows")
+    return y
+
+
+def softmax_rows_masked(x: torch.Tensor, keymask: torch.Tensor, q_pos0: int, scale: float = 1.0) -> torch.Tensor:
+    """x: [B, heads, q_rows, N] attention scores; keymask [B, N] (1 = key takes part); causal: query row i sees keys
+    <= q_pos0 + i.  Excluded keys get weight 0 (GPT-2 blocks of the sequence generator)."""
+    _chk(x, "softmax_masked.x")
+    _chk(keymask, "softmax_masked.keymask")
+    B, heads, q_rows, N = x.shape
+    assert keymask.shape == (B, N)
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_softmax_rows_masked(x.data_ptr(), y.data_ptr(), B, heads, q_rows, N, scale,
+                                                keymask.data_ptr(), q_pos0, _stream()), "softmax_rows_masked")
     return y
 
 

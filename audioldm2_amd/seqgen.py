@@ -1,0 +1,203 @@
+"""AudioMAE-token sequence generator on the MI355X — EXPERIMENTAL: written after round 1's GPU
+budget was spent; its host logic is verified on the CPU against the reference fixtures with the ops replaced by torch
+stand-ins (tests/test_host_logic.py), its first run on hardware is tests/test_seqgen_gpu.py (opt-in: ALDM_EXPERIMENTAL=1).
+
+Mirrors `Sequence2AudioMAE` (audioldm2/audiomae_gen/sequence_input.py): same constructor keywords, same state-dict keys
+(`start_of_sequence_tokens`, `end_of_sequence_tokens`, `input_sequence_embed_linear.{i}`, `model.{wte,wpe,h.{l}.*,ln_f}` with
+GPT-2's `Conv1D` weights stored [in, out]) and the same `generate(batch, cond_dict) -> (tokens [B, steps, 768], cond_dict)`.
+
+The reference re-runs GPT-2 over the whole prefix for every generated token (sequence_input.py:308-323; 512 full forwards
+for the speech model).  Here the prefix is run once and every later position attends to cached keys / values — the same
+function (oracle/seqgen.py: cached == full re-forward), O(n) instead of O(n^2) forwards.  The cache has a fixed length
+(prefix + steps, rounded up to 4): positions that do not exist yet are masked, so every step launches identical shapes.
+All arithmetic goes through the C ABI: `aldm_layernorm`, `aldm_igemm` (projections with fused bias / tanh-GELU /
+residual; Q·K^T as the NT batched product, P·V through `aldm_pack_kn`), `aldm_softmax_rows_masked`, `aldm_axpby`;
+torch only moves data (concatenation, head split / merge copies, cache writes).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU_TANH
+
+N_LAYER, N_HEAD, N_EMBD, HEAD_DIM, N_POS, LN_EPS = 12, 12, 768, 64, 1024, 1e-5  # GPT2Config defaults == "gpt2"
+
+
+class _Conv1D(nn.Module):
+    """transformers' Conv1D parameter layout: y = x @ weight + bias with weight [in, out]."""
+
+    def __init__(self, n_in: int, n_out: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n_in, n_out) * 0.02)
+        self.bias = nn.Parameter(torch.zeros(n_out))
+
+
+class _LN(nn.Module):
+    def __init__(self, n: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+
+
+class _Attn(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c_attn = _Conv1D(N_EMBD, 3 * N_EMBD)
+        self.c_proj = _Conv1D(N_EMBD, N_EMBD)
+
+
+class _MLP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c_fc = _Conv1D(N_EMBD, 4 * N_EMBD)
+        self.c_proj = _Conv1D(4 * N_EMBD, N_EMBD)
+
+
+class _Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.ln_1, self.attn, self.ln_2, self.mlp = _LN(N_EMBD), _Attn(), _LN(N_EMBD), _MLP()
+
+
+class _GPT2(nn.Module):
+    """Parameter container with GPT2Model's names; `wte` is never used (the generator feeds inputs_embeds) but is part of
+    the reference's state dict."""
+
+    def __init__(self):
+        super().__init__()
+        self.wte = nn.Embedding(50257, N_EMBD)
+        self.wpe = nn.Embedding(N_POS, N_EMBD)
+        self.h = nn.ModuleList([_Block() for _ in range(N_LAYER)])
+        self.ln_f = _LN(N_EMBD)
+
+
+def _f(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(dtype=torch.float32).contiguous()
+
+
+class Sequence2AudioMAE(nn.Module):
+    def __init__(self, base_learning_rate=None, sequence_gen_length: int = 8, sequence_input_key: Sequence[str] = (),
+                 sequence_input_embed_dim: Sequence[int] = (), cond_stage_config: Optional[dict] = None, **kwargs):
+        super().__init__()
+        self.mae_token_num = int(sequence_gen_length)
+        self.sequence_input_key = list(sequence_input_key)
+        self.sequence_input_embed_dim = list(sequence_input_embed_dim)
+        self.start_of_sequence_tokens = nn.Embedding(32, N_EMBD)
+        self.end_of_sequence_tokens = nn.Embedding(32, N_EMBD)
+        self.input_sequence_embed_linear = nn.ModuleList([nn.Linear(d, N_EMBD) for d in self.sequence_input_embed_dim])
+        self.model = _GPT2()
+        # conditioner sub-modules through the reference's plugin seam (sequence_input.py:372-383)
+        self.cond_stage_models = nn.ModuleList([])
+        self.cond_stage_model_metadata = {}
+        if cond_stage_config:
+            from .pipeline import instantiate_from_config
+            for i, (key, cfg) in enumerate(cond_stage_config.items()):
+                self.cond_stage_models.append(instantiate_from_config(cfg))
+                self.cond_stage_model_metadata[key] = {"model_idx": i, "cond_stage_key": cfg["cond_stage_key"],
+                                                       "conditioning_key": cfg["conditioning_key"]}
+        self._pk = None
+        self.eval()
+
+    # ---- packed weights (built once; invalidate_packed() after loading new weights) ---------------------------------
+    def invalidate_packed(self):
+        self._pk = None
+
+    def _packed(self):
+        if self._pk is None:
+            def conv1d(m):  # Conv1D [in, out] -> the Linear layout pack_conv expects
+                return ops.pack_conv(m.weight.detach().t().contiguous(), m.bias)
+            blocks = []
+            for b in self.model.h:
+                blocks.append(dict(ln1=(_f(b.ln_1.weight), _f(b.ln_1.bias)), ln2=(_f(b.ln_2.weight), _f(b.ln_2.bias)),
+                                   c_attn=conv1d(b.attn.c_attn), c_proj=conv1d(b.attn.c_proj),
+                                   c_fc=conv1d(b.mlp.c_fc), m_proj=conv1d(b.mlp.c_proj)))
+            self._pk = dict(blocks=blocks, ln_f=(_f(self.model.ln_f.weight), _f(self.model.ln_f.bias)),
+                            inp=[ops.pack_conv(l.weight, l.bias) for l in self.input_sequence_embed_linear],
+                            wpe=_f(self.model.wpe.weight), sos=_f(self.start_of_sequence_tokens.weight),
+                            eos=_f(self.end_of_sequence_tokens.weight))
+        return self._pk
+
+    # ---- sequence_input.py:136-199 (+ :109-124) -------------------------------------------------------------------
+    def get_input_sequence_and_mask(self, cond_dict: Dict[str, object]) -> Tuple[torch.Tensor, torch.Tensor, int]:
+        pk = self._packed()
+        embeds, masks = [], []
+        for i, key in enumerate(self.sequence_input_key):
+            assert key in cond_dict, "Invalid sequence key %s" % key
+            c = cond_dict[key]
+            if isinstance(c, (list, tuple)):
+                assert len(c) == 2, "The crossattn returned list should have length 2, including embed and attn_mask"
+                x, m = c
+            else:
+                x, m = c, torch.ones((c.shape[0], c.shape[1]), device=c.device)
+            x = ops.linear(x.to(torch.float32).contiguous(), pk["inp"][i])
+            B = x.shape[0]
+            one = torch.ones((B, 1), device=x.device)
+            embeds += [pk["sos"][i].expand(B, 1, -1), x, pk["eos"][i].expand(B, 1, -1)]
+            masks += [one, m.to(torch.float32), one]
+        x, m = torch.cat(embeds, dim=1), torch.cat(masks, dim=1)
+        max_len = N_POS - self.mae_token_num
+        if x.shape[1] > max_len:
+            print("The input sequence length to GPT-2 model is too long:", x.shape[1])
+            x, m = x[:, :max_len], m[:, :max_len]
+        return x.contiguous(), m.contiguous(), x.shape[1]
+
+    # ---- GPT-2 over T new positions starting at pos0, keys / values of every position in fixed-length caches -------
+    def _forward_positions(self, x: torch.Tensor, pos0: int, kc: List[torch.Tensor], vc: List[torch.Tensor],
+                           keymask: torch.Tensor) -> torch.Tensor:
+        pk = self._packed()
+        B, T, _ = x.shape
+        Z, n_tot = B * N_HEAD, keymask.shape[1]
+        pos = pk["wpe"][pos0:pos0 + T].expand(B, T, N_EMBD).contiguous()
+        h = ops.axpby(x.contiguous(), pos, 1.0, 1.0).view(B * T, N_EMBD)
+        for l, blk in enumerate(pk["blocks"]):
+            a = ops.layernorm(h, blk["ln1"][0], blk["ln1"][1], LN_EPS)
+            qkv = ops.linear(a, blk["c_attn"]).view(B, T, 3, N_HEAD, HEAD_DIM)
+            q = qkv[:, :, 0].permute(0, 2, 1, 3).reshape(Z, T, HEAD_DIM)              # head split: copies
+            kc[l].view(B, N_HEAD, n_tot, HEAD_DIM)[:, :, pos0:pos0 + T] = qkv[:, :, 1].permute(0, 2, 1, 3)
+            vc[l].view(B, N_HEAD, n_tot, HEAD_DIM)[:, :, pos0:pos0 + T] = qkv[:, :, 2].permute(0, 2, 1, 3)
+            s = ops.gemm_nt(q, kc[l], alpha=1.0 / math.sqrt(HEAD_DIM))               # [Z, T, n_tot]
+            p = ops.softmax_rows_masked(s.view(B, N_HEAD, T, n_tot), keymask, pos0)
+            o = ops.gemm_packed_batched(p.view(Z, T, n_tot), ops.pack_kn(vc[l]), n_tot, HEAD_DIM)  # [Z, T, 64]
+            o = o.view(B, N_HEAD, T, HEAD_DIM).permute(0, 2, 1, 3).reshape(B * T, N_EMBD)           # head merge: copy
+            h = ops.linear(o, blk["c_proj"], res=h)
+            m = ops.layernorm(h, blk["ln2"][0], blk["ln2"][1], LN_EPS)
+            m = ops.linear(m, blk["c_fc"], act=ACT_GELU_TANH)
+            h = ops.linear(m, blk["m_proj"], res=h)
+        return ops.layernorm(h, pk["ln_f"][0], pk["ln_f"][1], LN_EPS).view(B, T, N_EMBD)
+
+    # ---- sequence_input.py:294-325 -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, batch, cond_dict: Optional[dict] = None, no_grad: bool = False):
+        if cond_dict is None:
+            cond_dict = self.get_input(batch)
+        x, mask, P = self.get_input_sequence_and_mask(cond_dict)
+        B, steps = x.shape[0], self.mae_token_num
+        n_tot = (P + steps + 3) // 4 * 4
+        dev = x.device
+        kc = [torch.zeros((B * N_HEAD, n_tot, HEAD_DIM), device=dev) for _ in range(N_LAYER)]
+        vc = [torch.zeros((B * N_HEAD, n_tot, HEAD_DIM), device=dev) for _ in range(N_LAYER)]
+        keymask = torch.zeros((B, n_tot), device=dev)
+        keymask[:, :P] = mask
+        out = self._forward_positions(x, 0, kc, vc, keymask)
+        tok, toks = out[:, -1:, :].contiguous(), []
+        for t in range(steps):
+            toks.append(tok)
+            if t + 1 == steps:
+                break
+            keymask[:, P + t] = 1.0  # the token joins the sequence (its own key is visible to it)
+            tok = self._forward_positions(tok, P + t, kc, vc, keymask)
+        return torch.cat(toks, dim=1), cond_dict
+
+    # ---- conditioning through the sub-modules (sequence_input.py:327-370, 385-403) ---------------------------------
+    def get_input(self, batch) -> dict:
+        cond = {}
+        for key, meta in self.cond_stage_model_metadata.items():
+            k = meta["cond_stage_key"]
+            xc = batch if k == "all" else batch[k]
+            cond[key] = self.cond_stage_models[meta["model_idx"]](xc)
+        return cond

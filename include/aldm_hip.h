@@ -37,7 +37,8 @@ enum {
     ALDM_ACT_LRELU = 2,     /* leaky_relu(x, slope): hifigan/models.py:98,151,161           */
     ALDM_ACT_TANH = 3,      /* hifigan/models.py:163                                        */
     ALDM_ACT_LOGCLAMP = 4,  /* log(max(x, slope)): audio_processing.py:85-91 (clip 1e-5)    */
-    ALDM_ACT_GELU = 5       /* exact erf GELU: attention.py:44                              */
+    ALDM_ACT_GELU = 5,      /* exact erf GELU: attention.py:44                              */
+    ALDM_ACT_GELU_TANH = 6  /* tanh GELU ("gelu_new"): GPT-2 MLP of the sequence generator, sequence_input.py:69 */
 };
 
 /* epilogue modes of aldm_igemm.
@@ -200,6 +201,11 @@ int aldm_attention_mma(int mode);
 /* row softmax with pre-scale: y = softmax(scale * x) over the last dim of [M, N]
  * (model.py:220-221)                                                                        */
 int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale, void* stream);
+/* Causal + key-padding masked row softmax for attention score rows laid out [B, heads, q_rows, N] (GPT-2 blocks of the
+ * AudioMAE-token sequence generator, audiomae_gen/sequence_input.py:308-323 via transformers GPT2Attention): key j of
+ * batch b takes part iff keymask[b, j] != 0 and j <= q_pos0 + i for query row i; excluded keys get weight 0.       */
+int aldm_softmax_rows_masked(const float* x, float* y, int B, int heads, int q_rows, int N, float scale,
+                             const float* keymask, int q_pos0, void* stream);
 
 /* ---- elementwise ---------------------------------------------------------------------- */
 /* GEGLU gate: y[m, c] = x[m, c] * gelu_erf(x[m, C + c]), x: [M, 2C] (attention.py:42-44)   */
