@@ -11,14 +11,12 @@
 //                                                      online-softmax rescale is lane-local too.
 // The K-index permutation inside each MFMA is free (d index s pairs with 16+s; key (r&3)+8(r>>2)
 // pairs with the same +4), which is what makes both products transpose-free.
-#include "common.h"
+#include "igemm_epilogue.h"
 #include <float.h>
 #include <stdlib.h>
 
 namespace aldm {
 
-using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
-using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 
 // Exact 3-way split of 8 fp32 values (x = hi + mid + lo, each part the top 16 bits of an fp32) into three bf16x8
 // MFMA operands; element j of an operand is x[j].  Same arithmetic as the igemm engine's A-side split
@@ -52,7 +50,7 @@ template <bool HAS_MASK, int QT, bool BX = false>
 __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-    const float* __restrict__ mask, float scale) {
+    const float* __restrict__ mask, float scale, void* __restrict__ out_split, int split_c) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l31 = lane & 31;
@@ -218,13 +216,15 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         const float inv = 1.0f / l_tot;
         const int qi = q0 + 32 * t + l31;
         if (qi < Lq) {
-            float* op = out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh;
+            float* op = out ? out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh : nullptr;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 x;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
-                *reinterpret_cast<f32x4*>(op + 8 * g) = x;
+                if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
+                // a head = one 32-channel block of the split image (the out-projection GEMM's pre-split A operand)
+                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x);
             }
         }
     }
@@ -250,10 +250,13 @@ extern "C" int aldm_attention_mma(int mode) {
     return prev;
 }
 
-extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v, float* out, int B,
-                                  int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-                                  const float* mask, float scale, void* stream) {
-    ALDM_CHECK(q && k && v && out, "aldm_attention_d32: null pointer");
+static int attention_launch(const float* q, const float* k, const float* v, float* out, void* out_split, int B,
+                            int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                            const float* mask, float scale, void* stream) {
+    ALDM_CHECK(q && k && v && (out || out_split), "aldm_attention_d32: null pointer");
+    ALDM_CHECK((reinterpret_cast<uintptr_t>(out_split) & 15) == 0, "aldm_attention_d32: out_split must be 16-byte aligned");
+    const int split_c = heads * 32;
+    if (!out) ldo = heads * 32;
     ALDM_CHECK(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "aldm_attention_d32: bad sizes");
     ALDM_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0 && ldq >= heads * 32 &&
                    ldk >= heads * 32 && ldv >= heads * 32 && ldo >= heads * 32,
@@ -274,7 +277,7 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
 #define ALDM_ATTN(M_, Q_, X_)                                                                                 \
     hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
-                       ldk, ldv, ldo, mask, scale)
+                       ldk, ldv, ldo, mask, scale, out_split, split_c)
 #define ALDM_ATTN_X(M_, Q_)          \
     do {                             \
         if (bx) ALDM_ATTN(M_, Q_, true); \
@@ -291,4 +294,17 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
 #undef ALDM_ATTN
     ALDM_LAUNCH_CHECK("aldm_attention_d32");
     return 0;
+}
+
+extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v, float* out, int B,
+                                  int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                                  const float* mask, float scale, void* stream) {
+    ALDM_CHECK(out != nullptr, "aldm_attention_d32: null pointer");
+    return attention_launch(q, k, v, out, nullptr, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, mask, scale, stream);
+}
+
+extern "C" int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
+                                        int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                                        const float* mask, float scale, void* stream) {
+    return attention_launch(q, k, v, out, out_split, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, mask, scale, stream);
 }

@@ -19,6 +19,10 @@ int igemm_launch_bx_pre1(int BM, int BN, int kgroups, bool uni, bool w8, dim3 gr
 int igemm_launch_bx_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_launch_bx_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 
+// DMA-fed kernel over pre-split operands (igemm_dma.hip)
+int igemm_launch_dma(int BM, int BN, int nst, dim3 grid, hipStream_t st, const IgemmK& p);
+bool igemm_dma_config_ok(int BM, int BN, int nst);
+
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
 __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
@@ -53,10 +57,17 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
         if ((unsigned)t >= (unsigned)d.out_len) return;
         orow = (int64_t)b * d.out_len + t;
     }
-    float* outp = d.out + (int64_t)z * d.stride_o;
+    float* outp = d.out ? d.out + (int64_t)z * d.stride_o : nullptr;
     const float* resp = d.res ? d.res + (int64_t)z * d.stride_o : nullptr;
+    const int64_t o = orow * d.ldo + n;
+    f32x4 r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) epi_store(d, p.rb_ld, outp, resp, b, orow, n + j, v[j]);
+    for (int j = 0; j < 4; ++j) r[j] = epi_value(d, p.rb_ld, outp, resp, b, o + j, n + j, v[j]);
+    if (outp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) outp[o + j] = r[j];
+    }
+    if (d.out_split) split_store4(d.out_split, orow, d.out_split_c, n, r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,14 +184,16 @@ static int log2_exact(int v) {
 
 using namespace aldm;
 
-static thread_local int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0, g_force_kgroups = 0;
+static thread_local int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0, g_force_kgroups = 0, g_force_stages = 0;
 
 extern "C" void aldm_igemm_force(int bm, int bn, int splits, int kgroups) {
     g_force_bm = bm;
     g_force_bn = bn;
     g_force_splits = splits;
     g_force_kgroups = kgroups;
+    g_force_stages = 0;
 }
+extern "C" void aldm_igemm_force_stages(int stages) { g_force_stages = stages; }
 
 static int default_wave8_mask() {
     static const int m = [] {
@@ -222,7 +235,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(dd != nullptr, "aldm_igemm: null descriptor");
     p.d = *dd;
     aldm_igemm_desc& d = p.d;
-    ALDM_CHECK(d.x1 && d.w && d.out, "aldm_igemm: null x1/w/out");
+    ALDM_CHECK((d.x1 || d.a_split) && d.w && (d.out || d.out_split), "aldm_igemm: null x1/w/out");
+    if (!d.x1) d.x1 = reinterpret_cast<const float*>(d.a_split);  // never dereferenced on the DMA path
     if (!d.x2) d.C2 = 0;
     if (d.pix1 == 0) d.pix1 = d.C1;
     if (d.pix2 == 0) d.pix2 = d.C2;
@@ -292,6 +306,97 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     // time), the LDS image is 1.5x larger (1 / 2 / 3 resident blocks for the three tile sizes) and staging
     // pays the operand split.
     const int pre = pre_mode_of(d);
+    p.dma = 0;
+    p.nst = 0;
+    if (d.out_split) {
+        ALDM_CHECK(d.out_split_c > 0 && d.out_split_c % 32 == 0 && d.out_split_c >= (geglu ? d.N / 2 : d.N) &&
+                       d.N % 4 == 0 && d.batch == 1 && (reinterpret_cast<uintptr_t>(d.out_split) & 15) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res)) & 15) == 0 &&
+                       (d.out == nullptr || (d.ldo & 3) == 0),
+                   "aldm_igemm: out_split needs out_split_c %% 32 == 0 and >= N, N %% 4 == 0, batch 1, aligned out/res");
+        ALDM_CHECK(d.out != nullptr || !d.accumulate, "aldm_igemm: accumulate needs an fp32 output");
+    }
+    if (d.a_split) {
+        // ---- DMA-fed kernel over pre-split operands (igemm_dma.h) ----
+        ALDM_CHECK(d.w_split != nullptr && d.b_mode == ALDM_B_PACKED && d.stride_w == 0 && d.batch == 1,
+                   "aldm_igemm: a_split needs packed, split weights and batch 1");
+        ALDM_CHECK(d.C2 == 0 && d.C1 % 32 == 0 && pre == PRE_NONE,
+                   "aldm_igemm: a_split needs one source with C1 %% 32 == 0 and no prologue (C1=%d C2=%d)", d.C1, d.C2);
+        ALDM_CHECK(((reinterpret_cast<uintptr_t>(d.a_split) | reinterpret_cast<uintptr_t>(d.w_split)) & 15) == 0,
+                   "aldm_igemm: split images must be 16-byte aligned");
+        ALDM_CHECK((int64_t)d.B * d.H * d.W * p.Cin * 6 < (1ll << 40), "aldm_igemm: split image too large");
+        const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu;
+        const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
+        auto dma_cost = [&](int bm, int bn, int nst, int sp, int* sp_eff) -> double {
+            const int kt = cdiv(nk, sp);
+            sp = cdiv(nk, kt);
+            *sp_eff = sp;
+            const double blocks = (double)cdiv64(Mz, bm) * cdiv(d.N, bn) * sp;
+            const int lds = nst * (bm + bn) * 192;
+            const int o = std::min(2, (160 * 1024) / lds);
+            const double tile_c = (bm / 64) * (bn / 64) * 384.0;   // MFMA cycles of one wave per k-tile
+            const double dma_c = (bm + bn) * 192.0 / 56.0;         // L2 -> LDS at ~56 B/clk/CU
+            const double L = kt * std::max(tile_c, dma_c);
+            const double one = kt * std::max(tile_c + 200.0, dma_c) + 6000.0;
+            const int64_t nb = (int64_t)((blocks + 255.0) / 256.0);
+            const int64_t full = nb / o, last = nb - full * o;
+            double T = full * std::max(one, o * L);
+            if (last) T += std::max(one, last * L);
+            if (sp > 1) T += 10000.0 + (double)(sp + 1) * Mz * d.N * 4.0 / 2000.0;
+            return T;
+        };
+        int splits = 1, nst = 0;
+        const int f_bm = g_force_bm ? g_force_bm : d.hint_bm, f_bn = g_force_bm ? g_force_bn : d.hint_bn;
+        const int f_sp = g_force_bm ? g_force_splits : d.hint_splits;
+        const int f_st = g_force_bm ? g_force_stages : d.hint_stages;
+        if (f_bm) {
+            BM = f_bm;
+            BN = f_bn;
+            nst = f_st > 0 ? f_st : (BM == 256 ? 2 : (BM == 128 && BN == 128 ? 3 : (BM == 64 && BN == 64 ? 3 : 4)));
+            ALDM_CHECK(igemm_dma_config_ok(BM, BN, nst), "aldm_igemm: no DMA kernel for tile %dx%d, %d stages", BM, BN, nst);
+            if (f_sp > 0 && can_split && nk / f_sp >= 1) splits = f_sp;
+        } else {
+            static const int cand[4][3] = {{128, 128, 3}, {64, 128, 4}, {128, 64, 4}, {64, 64, 3}};
+            static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+            double best = 1e300;
+            BM = BN = 64;
+            nst = 3;
+            for (int c = 0; c < 4; ++c) {
+                const int bm = cand[c][0], bn = cand[c][1];
+                if (geglu ? bn != 128 : (bn > 64 && d.N <= 64)) continue;
+                for (int si = 0; si < 8; ++si) {
+                    const int sp = sps[si];
+                    if (sp > 1 && (!can_split || !have_ws || nk / sp < 3)) break;
+                    int spe;
+                    const double t = dma_cost(bm, bn, cand[c][2], sp, &spe);
+                    if (spe > 1 && (int64_t)spe * Mz * d.N > d.ws_floats) continue;
+                    if (t < best) {
+                        best = t;
+                        BM = bm;
+                        BN = bn;
+                        nst = cand[c][2];
+                        splits = spe;
+                    }
+                }
+            }
+        }
+        ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: the GEGLU epilogue needs a 128-column tile");
+        p.tiles_m = cdiv(p.M, BM);
+        p.tiles_n = cdiv(d.N, BN);
+        p.kt_per_split = cdiv(nk, splits);
+        splits = cdiv(nk, p.kt_per_split);
+        if (splits > 1 && (!have_ws || d.ws_floats < (int64_t)splits * p.M * d.N)) {
+            splits = 1;
+            p.kt_per_split = nk;
+        }
+        p.splits = splits;
+        p.kgroups = 1;
+        p.bx = 1;
+        p.pre = pre;
+        p.dma = 1;
+        p.nst = nst;
+        return 0;
+    }
     const bool bx_ok = d.w_split != nullptr && d.b_mode == ALDM_B_PACKED && d.stride_w == 0 && d.batch == 1 &&
                        pre != PRE_GENERIC && (reinterpret_cast<uintptr_t>(d.w_split) & 15) == 0 &&
                        (g_force_mma == 2 || (g_force_mma == 0 && d.hint_mma != 1));
@@ -439,7 +544,9 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     // BX: the 128x128 image leaves room for one block per CU, so that tile takes 8 waves for every prologue
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
                     (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
-    if (p.bx) {
+    if (p.dma) {
+        rc = igemm_launch_dma(BM, BN, p.nst, grid, st, p);
+    } else if (p.bx) {
         switch (pre) {
             case PRE_NONE: rc = igemm_launch_bx_pre0(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
             case PRE_AFFINE: rc = igemm_launch_bx_pre1(BM, BN, p.kgroups, uni, w8, grid, st, p); break;

@@ -1,0 +1,318 @@
+// igemm_dma.h — the DMA-fed bf16-split implicit-GEMM kernel: both operands arrive PRE-SPLIT.
+//
+//   out[m, n] = epi( sum_k A[m, k] * W[k, n] ),  m = (b, oh, ow), k = (kh, kw, ci)
+//
+// Same contraction, same "BF16x6" arithmetic (fp32 product = 6 bf16 partial products of exact 3-way operand splits,
+// fp32 accumulate on v_mfma_f32_32x32x16_bf16) and same epilogue as igemm_kernel<.., BX = true>, but the K loop holds
+// nothing except LDS-DMA issues, fragment reads and MFMAs:
+//  * A is a split image [pixel][C/32][3 parts][32] bf16 written by its producer (aldm_split_rows = GroupNorm apply +
+//    SiLU + split in ONE pass per element instead of once per tap and N-tile inside the K loop; aldm_layernorm_split;
+//    the attention and GEMM epilogues).  A conv tap is still pure address generation: per row and tap one pointer,
+//    zero padding = a pointer to a zero page;
+//  * W is the split image aldm_pack_split_bf16 writes, [k-octet][part][Npad][8 bf16];
+//  * both go global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write, no VALU).  An LDS-DMA
+//    instruction writes 64 lanes x 16 B contiguously, so the LDS image is whatever order the lanes fetch in:
+//      A chunk (16 rows, one part) = [16 rows][4 k-octets] 16-byte slots, the octet XOR-swizzled by (row >> 2) & 3 on the
+//        SOURCE address and on the fragment read (a ds_read_b128 lane group covers rows {r, r+12.., r+20..}: 16 distinct
+//        slots mod 16 -> conflict free), each row reading 64 contiguous bytes;
+//      B chunk = 64 consecutive columns of one (octet, part) row = 1 KB contiguous in HBM and in LDS;
+//  * NST-deep LDS ring (3 for the 128x128 tile: 144 KB), ONE raw s_barrier per 32-wide k-tile, placed between the
+//    tile's two 16-wide k-steps: before it the wave has read all its fragments of tile t and waits (counted vmcnt,
+//    never 0 in steady state) for its own DMA of tile t+1; after it tile t's buffer is free, so tile t+NST is issued
+//    there and the next tile's first fragments are read under the second k-step's MFMAs.  A wave is never without
+//    queued MFMAs except across the barrier itself;
+//  * WM x 2 waves, each a 64 x 64 (or 32-wide, for the 64-row / 64-column blocks) patch of 32x32 MFMA tiles: 12
+//    ds_read_b128 per 24 MFMAs (0.5 per MFMA; the register-staged kernel's 8-wave tile: 0.75).  128x128 = 4 waves, one
+//    per SIMD; 256x128 = 8 waves (two per SIMD, 2-deep ring of 72 KB stages), 25 % less LDS-DMA traffic per MFMA.
+// Restrictions (host checked): C1 % 32 == 0 (every k-tile lies in one tap), no second source tensor, no prologue,
+// packed + split weights, batch 1.  Everything else (stride, dilation, padding, nearest upsample, split-K, row remap,
+// GEGLU, split-image output) as in igemm_kernel.h.
+#pragma once
+#include "igemm_epilogue.h"
+#include <type_traits>
+
+namespace aldm {
+
+// zero padding / out-of-range columns are fetched from here (one copy per translation unit)
+static __device__ __attribute__((aligned(256))) unsigned g_dma_zero_page[256 + 64];
+
+constexpr int dma_stage_slots(int BM, int BN) { return (BM + BN) * 12; }   // 16-byte slots of one k-tile image
+constexpr int dma_lds_bytes(int BM, int BN, int NST) { return NST * dma_stage_slots(BM, BN) * 16; }
+constexpr int dma_blocks_per_cu(int BM, int BN, int NST) {
+    return (160 * 1024) / dma_lds_bytes(BM, BN, NST) >= 2 ? 2 : 1;
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14):
+// hipcc's own counter model sees it, so the fragment reads issued after the barrier are not waited for together with
+// the (already retired) older ones — an inline-asm wait is invisible to that model and cost an lgkmcnt(0) in front of
+// the second k-step's MFMAs.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
+#ifndef ALDM_DMA_ABLATE
+#define ALDM_DMA_ABLATE 0  // debug builds only (tools/gpu/build_variant.sh): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads
+#endif
+
+// WM x 2 waves (WM = 2: 256 threads, one wave per SIMD and block; WM = 4: 512 threads, the 256-row tiles)
+template <int BM, int BN, int NST, int WM = 2>
+__global__ __launch_bounds__(128 * WM, dma_blocks_per_cu(BM, BN, NST) * (WM / 2))
+void igemm_dma_kernel(const IgemmK p) {
+    constexpr int WN = 2, NW = WM * WN;
+    constexpr int MT = BM / (32 * WM), NT = BN / 64;
+    constexpr int STG = dma_stage_slots(BM, BN);
+    constexpr int RA = BM / (16 * NW);        // A row groups (16 rows x 3 parts) per wave = A rows per thread
+    constexpr int NB = 12 * (BN / 64) / NW;   // B chunks per wave
+    constexpr int D = 3 * RA + NB;            // LDS-DMA instructions per thread and k-tile
+    static_assert(BM % (16 * NW) == 0 && (12 * (BN / 64)) % NW == 0, "DMA chunks must divide among the waves");
+    static_assert(NST >= 2 && NST <= 4 && (NST - 1) * D <= 63, "ring depth / vmcnt range");
+    static_assert(NW * 32 * (NT * 32 + 4) * 4 <= NST * STG * 16, "epilogue staging must fit the ring");
+    __shared__ u32x4 smem[NST * STG];   // the ONLY LDS object (a second one makes hipcc drain vmcnt before every ds_read)
+
+    const aldm_igemm_desc& d = p.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware bijective remap of the linear block id (block b runs on XCD b % 8)
+    int tile_m, tile_n;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = logical % p.tiles_n;
+        tile_m = logical / p.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int nk_all = d.K >> 5;
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = min(nk_all, kt0 + p.kt_per_split);
+    const int nk = kt1 - kt0;
+
+    const char* zero = reinterpret_cast<const char*>(g_dma_zero_page);
+    const char* abase = reinterpret_cast<const char*>(d.a_split);
+    const char* wbase = reinterpret_cast<const char*>(d.w_split);
+    const int cpb = p.Cin >> 5;                       // k-tiles (32-channel blocks) per tap
+    const int64_t rowbytes = (int64_t)cpb * SPLIT_BLOCK_BYTES;
+
+    // ---- A bookkeeping: this thread fetches row (wave*RA + i)*16 + lane/4, slot lane%4 of each of the 3 parts ----
+    const int lane_off = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;   // swizzled source octet of this lane's LDS slot
+    int a_pix[RA], a_h[RA], a_w[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + (wave * RA + i) * 16 + (lane >> 2);
+        if (m < p.M) {
+            const int b = m / p.OHW;
+            const int rem = m - b * p.OHW;
+            const int oh = rem / d.OW;
+            const int ow = rem - oh * d.OW;
+            a_pix[i] = b * d.H;
+            a_h[i] = oh * d.SH - d.PH;
+            a_w[i] = ow * d.SW - d.PW;
+        } else {
+            a_pix[i] = 0;
+            a_h[i] = -(1 << 28);
+            a_w[i] = 0;
+        }
+    }
+    const char* a_ptr[RA];
+    int a_step[RA];
+    int t_kh, t_kw, t_cb;   // (tap, channel block) of the NEXT k-tile to issue
+    auto set_tap = [&]() {
+        const int dh = t_kh * d.DH, dw = t_kw * d.DW;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int ihv = a_h[i] + dh, iwv = a_w[i] + dw;
+            const bool ok = (unsigned)ihv < (unsigned)p.HV && (unsigned)iwv < (unsigned)p.WV;
+            const int pix = (a_pix[i] + (ihv >> p.shh)) * d.W + (iwv >> p.shw);
+            a_ptr[i] = (ok ? abase + (int64_t)pix * rowbytes : zero) + lane_off;
+            a_step[i] = ok ? SPLIT_BLOCK_BYTES : 0;
+        }
+    };
+    {
+        const int tap = kt0 / cpb;
+        t_cb = kt0 - tap * cpb;
+        t_kh = tap / d.KW;
+        t_kw = tap - t_kh * d.KW;
+        set_tap();
+#pragma unroll
+        for (int i = 0; i < RA; ++i) a_ptr[i] += (int64_t)t_cb * a_step[i];
+    }
+    // ---- B bookkeeping: chunk c = wave*NB + j -> (slot row = octet*3 + part, 64-column half) ----
+    const char* b_ptr[NB];
+    int64_t b_step[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int c = wave * NB + j;
+        const int srow = c / (BN / 64), half = c % (BN / 64);
+        const int col = n0 + half * 64 + lane;
+        const bool ok = col < p.Npad;
+        b_ptr[j] = ok ? wbase + (((int64_t)kt0 * 12 + srow) * p.Npad + col) * 16 : zero;
+        b_step[j] = ok ? (int64_t)12 * p.Npad * 16 : 0;
+    }
+
+    using gptr_t = const __attribute__((address_space(1))) void*;
+    using lptr_t = __attribute__((address_space(3))) void*;
+    // issues the next k-tile of this block into ring stage `st` (branch free: it is interleaved with MFMAs) ...
+    auto issue_dma = [&](int st) {
+        u32x4* sa = &smem[st * STG];
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const char* src = (ALDM_DMA_ABLATE & 1) ? zero + lane * 16 : a_ptr[i] + q * 64;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + ((wave * RA + i) * 3 + q) * 64), 16, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int c = wave * NB + j;
+            const int srow = c / (BN / 64), half = c % (BN / 64);
+            const char* src = (ALDM_DMA_ABLATE & 2) ? zero + lane * 16 : b_ptr[j];
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + BM * 12 + srow * BN + half * 64), 16, 0, 0);
+        }
+    };
+    // ... and advances the gather state to the k-tile after it
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) a_ptr[i] += a_step[i];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b_ptr[j] += b_step[j];
+        if (++t_cb == cpb) {   // next tile starts another tap: new row pointers
+            t_cb = 0;
+            if (++t_kw == d.KW) {
+                t_kw = 0;
+                ++t_kh;
+            }
+            set_tap();
+        }
+    };
+    auto issue = [&](int st) {
+        issue_dma(st);
+        advance();
+    };
+
+    // fragments of one 16-wide k-step: lane half lh owns k-octet 2*step + lh of both operands
+    struct Frag {
+        bf16x8 a[MT][3], b[NT][3];
+    };
+    const int a_sw = (l31 >> 2) & 3;
+    auto read_frags = [&](Frag& f, int st, int step) {
+#if ALDM_DMA_ABLATE & 8
+        return;
+#endif
+        const u32x4* sa = &smem[st * STG];
+        const int o = 2 * step + lh;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = (wm * MT + i) * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                f.a[i][q] = __builtin_bit_cast(bf16x8, sa[((row >> 4) * 3 + q) * 64 + (row & 15) * 4 + (o ^ a_sw)]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                f.b[j][q] = __builtin_bit_cast(bf16x8, sa[BM * 12 + (o * 3 + q) * BN + (wn * NT + j) * 32 + l31]);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mma_frags = [&](const Frag& f) {
+        constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};   // smallest partial products first
+#if ALDM_DMA_ABLATE & 4
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.a[i][q]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.b[j][q]));
+        return;
+#endif
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j], 0, 0, 0);
+    };
+    // wait until at most `n` k-tiles of this thread's DMA are still in flight (n is wave uniform)
+    auto wait_tiles = [&](int n) {
+        if (n <= 0) wait_vmcnt<0>();
+        else if (n == 1) wait_vmcnt<D>();
+        else if (n == 2) wait_vmcnt<(NST > 2 ? 2 : 1) * D>();
+        else wait_vmcnt<(NST > 3 ? 3 : 1) * D>();
+    };
+
+    // ---- K loop ----------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NST; ++s)
+        if (s < nk) issue(s);
+    wait_tiles(min(nk, NST) - 1);
+    __builtin_amdgcn_s_barrier();
+    Frag f0, f1;
+#if ALDM_DMA_ABLATE & 8
+    for (int q = 0; q < 3; ++q) {
+        for (int i = 0; i < MT; ++i) f0.a[i][q] = f1.a[i][q] = __builtin_bit_cast(bf16x8, smem[lane + q]);
+        for (int j = 0; j < NT; ++j) f0.b[j][q] = f1.b[j][q] = __builtin_bit_cast(bf16x8, smem[lane + 64 + q]);
+    }
+#endif
+    read_frags(f0, 0, 0);
+    int st = 0, t = 0;
+    // one k-tile with a successor: k-step 0's MFMAs | wait + barrier | (issue tile t+NST) | next tile's first fragments
+    // under k-step 1's MFMAs.  STEADY: tile t+NST exists, so NST-2 tiles stay in flight across the barrier — no
+    // data-dependent branch and no control-flow join between the fragment reads and their MFMAs (at a join hipcc
+    // merges its LDS counters to lgkmcnt(0), i.e. the fresh reads would be waited for before the first MFMA).
+    auto body = [&](auto steady) {
+        constexpr bool ST = decltype(steady)::value;
+        constexpr int NMF = 6 * MT * NT, NRD = 3 * (MT + NT);
+        read_frags(f1, st, 1);
+        mma_frags(f0);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {   // one fragment read behind each of the first MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int st1 = st + 1 == NST ? 0 : st + 1;
+        // the wait includes lgkmcnt(0): this wave is done reading stage `st`
+        if constexpr (ST) wait_vmcnt<(NST - 2) * D>();
+        else wait_tiles(min(NST - 2, nk - 2 - t));   // tiles t+2 .. nk-1 may stay in flight
+        __builtin_amdgcn_s_barrier();
+        if constexpr (ST) issue_dma(st);
+        read_frags(f0, st1, 0);
+        mma_frags(f1);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {   // MFMA first, the DMA issues and the next fragments in its shadow
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            if (ST && q == 0) __builtin_amdgcn_sched_group_barrier(0x020, D, 1);
+            if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ST) advance();
+        st = st1;
+    };
+    for (; t + NST < nk; ++t) body(std::true_type{});
+    for (; t + 1 < nk; ++t) body(std::false_type{});
+    read_frags(f1, st, 1);   // last tile
+    mma_frags(f0);
+    mma_frags(f1);
+
+    __syncthreads();   // every wave is past its last fragment read; nothing is in flight
+    igemm_epilogue<MT, NT>(p, acc, reinterpret_cast<float*>(&smem[0]), m0, n0, wave, wm, wn, lane, 0, split);
+}
+
+}  // namespace aldm

@@ -1,0 +1,122 @@
+// igemm_dma.hip — instantiations of the DMA-fed bf16-split implicit-GEMM kernel (igemm_dma.h) and the split-image
+// producers that feed it: aldm_split_rows (GroupNorm apply + activation + 3-way split in one pass over the tensor).
+#include "igemm_dma.h"
+
+namespace aldm {
+
+bool igemm_dma_config_ok(int BM, int BN, int nst) {
+    if (BM == 256 && BN == 128) return nst == 2;
+    if (BM == 128 && BN == 128) return nst == 2 || nst == 3;
+    if ((BM == 64 && BN == 128) || (BM == 128 && BN == 64)) return nst == 2 || nst == 4;
+    if (BM == 64 && BN == 64) return nst == 2 || nst == 3;
+    return false;
+}
+
+int igemm_launch_dma(int BM, int BN, int nst, dim3 grid, hipStream_t st, const IgemmK& p) {
+#define ALDM_DMA(BM_, BN_, NST_) \
+    hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_>), grid, dim3(256), 0, st, p)
+    if (BM == 256 && BN == 128 && nst == 2)
+        hipLaunchKernelGGL((igemm_dma_kernel<256, 128, 2, 4>), grid, dim3(512), 0, st, p);
+    else if (BM == 128 && BN == 128 && nst == 3) ALDM_DMA(128, 128, 3);
+    else if (BM == 128 && BN == 128 && nst == 2) ALDM_DMA(128, 128, 2);
+    else if (BM == 64 && BN == 128 && nst == 4) ALDM_DMA(64, 128, 4);
+    else if (BM == 64 && BN == 128 && nst == 2) ALDM_DMA(64, 128, 2);
+    else if (BM == 128 && BN == 64 && nst == 4) ALDM_DMA(128, 64, 4);
+    else if (BM == 128 && BN == 64 && nst == 2) ALDM_DMA(128, 64, 2);
+    else if (BM == 64 && BN == 64 && nst == 3) ALDM_DMA(64, 64, 3);
+    else if (BM == 64 && BN == 64 && nst == 2) ALDM_DMA(64, 64, 2);
+    else return -1;
+#undef ALDM_DMA
+    return 0;
+}
+
+// ---- split-image producer -------------------------------------------------------------------------------------
+// dst[row][c] = split(act(x[row][c] * scale[b, c] + shift[b, c])), x = x1 ++ x2 along C (channels-last rows, P rows
+// per sample); scale == NULL: no affine.  dst_raw (optional) = split(x) of the same concatenated rows (the operand of
+// a ResBlock's 1x1 skip conv).  One thread = 8 consecutive channels of one row: two 16-byte loads, three (six)
+// 16-byte stores; 4 neighbouring lanes cover one 192-byte block.
+template <int ACT, bool AFF>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                         int C1, int C2, int64_t rows, int P,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, char* __restrict__ dst,
+                                                         char* __restrict__ dst_raw) {
+    const int C = C1 + C2;
+    const int C8 = C >> 3;
+    const int64_t total = rows * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) << 3;
+        const float* src = c < C1 ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const int64_t off = (row * (C >> 5) + (c >> 5)) * SPLIT_BLOCK_BYTES + (c & 31) * 2;
+        u32x2 p0[3], p1[3];
+        if (dst_raw) {
+            split4(v0, p0);
+            split4(v1, p1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<u32x4*>(dst_raw + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+        }
+        if constexpr (AFF) {
+            const int64_t so = (row / P) * C + c;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + so), s1 = *reinterpret_cast<const f32x4*>(scale + so + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + so), h1 = *reinterpret_cast<const f32x4*>(shift + so + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // one rounding per element: matters when |mean| >> std (shift ~ -mean * scale)
+                v0[e] = __builtin_fmaf(v0[e], s0[e], h0[e]);
+                v1[e] = __builtin_fmaf(v1[e], s1[e], h1[e]);
+            }
+        }
+        if constexpr (ACT == ALDM_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = silu_fast(v0[e]);
+                v1[e] = silu_fast(v1[e]);
+            }
+        }
+        split4(v0, p0);
+        split4(v1, p1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            *reinterpret_cast<u32x4*>(dst + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+    }
+}
+
+}  // namespace aldm
+
+using namespace aldm;
+
+extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C) { return rows * (int64_t)(C / 32) * SPLIT_BLOCK_BYTES; }
+
+extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                               const float* shift, int act, void* dst, void* dst_raw, void* stream) {
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    ALDM_CHECK(x1 && dst && rows > 0 && P > 0, "aldm_split_rows: bad args");
+    ALDM_CHECK(C % 32 == 0 && C1 % 8 == 0 && C2 % 8 == 0, "aldm_split_rows: need (C1+C2) %% 32 == 0, C1 %% 8 == 0 (C1=%d C2=%d)",
+               C1, C2);
+    ALDM_CHECK((scale == nullptr) == (shift == nullptr), "aldm_split_rows: scale/shift must come together");
+    ALDM_CHECK(act == ALDM_ACT_NONE || act == ALDM_ACT_SILU, "aldm_split_rows: activation %d not supported", act);
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(dst) |
+                 reinterpret_cast<uintptr_t>(dst_raw) | reinterpret_cast<uintptr_t>(scale) |
+                 reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
+               "aldm_split_rows: operands must be 16-byte aligned");
+    const int64_t total = rows * (C >> 3);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipStream_t st = (hipStream_t)stream;
+#define ALDM_SPLIT(A_, F_)                                                                                        \
+    hipLaunchKernelGGL((split_rows_kernel<A_, F_>), dim3(blocks), dim3(256), 0, st, x1, x2, C1, C2, rows, P, scale, \
+                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw))
+    if (scale) {
+        if (act == ALDM_ACT_SILU) ALDM_SPLIT(ALDM_ACT_SILU, true);
+        else ALDM_SPLIT(ALDM_ACT_NONE, true);
+    } else {
+        if (act == ALDM_ACT_SILU) ALDM_SPLIT(ALDM_ACT_SILU, false);
+        else ALDM_SPLIT(ALDM_ACT_NONE, false);
+    }
+#undef ALDM_SPLIT
+    ALDM_LAUNCH_CHECK("aldm_split_rows");
+    return 0;
+}

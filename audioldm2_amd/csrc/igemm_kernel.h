@@ -29,22 +29,11 @@
 // The bullets on the LDS image and the software pipeline describe the fp32-MFMA instantiations; the BX ones keep
 // gather, prologues, epilogues and split-K but use a 12-slot bf16 image and a deeper pipeline (below).
 #pragma once
-#include "common.h"
+#include "igemm_epilogue.h"
 #include <type_traits>
 
 namespace aldm {
 
-struct IgemmK {
-    aldm_igemm_desc d;
-    int Cin, M, OHW, HV, WV, shh, shw, Kg, Npad, tiles_m, tiles_n;
-    int splits, kt_per_split;  // split-K: k-tiles [s*kt_per_split, ...) per blockIdx.y
-    int kgroups;               // wave groups per block (1 or 2, see igemm_kernel)
-    int rb_ld;                 // row-bias pitch
-    int bx;                    // 1: bf16-split kernels (d.w_split), 0: fp32 MFMA
-    int pre;                   // PRE_* prologue mode of the descriptor
-};
-
-enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4 };
 
 #ifndef ALDM_BX_INTERLEAVE
 #define ALDM_BX_INTERLEAVE 1
@@ -58,31 +47,7 @@ enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GEN
 #define ALDM_ABLATE 0  // debug builds only (tools/gpu/build_ablate.sh): drop pieces of the BX K loop to time the rest
 #endif
 constexpr int BK = 32;
-using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
-using u32x2 = unsigned __attribute__((ext_vector_type(2)));
-// the upper halves of two dwords as one dword (lo half from a): two truncated bf16 side by side
-__device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 constexpr int KG = BK / 4;
-
-// one output element through the fused epilogue (shared by the GEMM kernel and the split-K reduce)
-__device__ __forceinline__ void epi_store(const aldm_igemm_desc& d, int rb_ld, float* __restrict__ outp,
-                                          const float* __restrict__ resp, int b, int64_t orow, int n,
-                                          float v) {
-    if (d.bias) v += d.bias[n];
-    if (d.rowbias) v += d.rowbias[(int64_t)b * rb_ld + n];
-    v = act_apply(v, d.act, d.act_slope);
-    const int64_t o = orow * d.ldo + n;
-    if (resp) v += resp[o];
-    v *= d.alpha;
-    if (d.accumulate) v += outp[o];
-    outp[o] = v;
-}
-
-__device__ __forceinline__ float silu_fast(float v) {
-    // x * sigmoid(x); v_exp_f32 / v_rcp_f32 are <= 1 ulp each: ~1e-7 relative, far inside the
-    // parity tolerance, and 5 VALU ops instead of the ~25 of expf + IEEE division.
-    return v * __frcp_rn(1.0f + __expf(-v));
-}
 
 // resident blocks per CU the register budget must allow (LDS allows 2 / 3 / 4 for the three tile sizes)
 constexpr int igemm_min_blocks(int BM, int BN) {
@@ -615,18 +580,8 @@ void igemm_kernel(const IgemmK p) {
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------
-    // The MFMA accumulator layout gives a lane 4-byte pieces of 16 different rows; storing those
-    // directly is store-issue bound (one dword store instruction per element).  Instead each wave
-    // transposes its 32 x (NT*32) slab through its private LDS region and every lane then owns
-    // float4s along N: bias / residual / previous-output loads and the stores are 16 bytes wide,
-    // all optional operands are fetched with unconditional loads from clamped addresses.
-    //   v = act(acc + bias + rowbias); v = alpha*(v + res); out = accumulate ? out + v : v
+    // ---- epilogue (igemm_epilogue.h): each wave transposes its slab through a private LDS region -----
     constexpr int SP = NT * 32 + 4;   // staging row pitch (floats); +4 keeps 16-byte alignment
-    constexpr int C4 = NT * 8;        // float4 per staged row
-    constexpr int RPI = 64 / C4;      // rows covered by one wave-wide float4 read
-    constexpr int IT = 32 / RPI;      // reads per 32-row slab
-    constexpr int ITC = IT < 4 ? IT : 4;  // ... processed ITC at a time
     static_assert(WM * WN * 32 * SP * 4 <= (A_F4 + B_F4) * 16, "staging must fit the K-loop LDS");
     __syncthreads();  // every wave is done reading As/Bs
     if constexpr (KGRP == 2) {
@@ -651,159 +606,7 @@ void igemm_kernel(const IgemmK p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * NT + j) * 16 + e) * 64];
     }
-    float* stg = reinterpret_cast<float*>(&smem[0]) + wave * (32 * SP);
-    const int sr = lane / C4;          // row within an RPI group
-    const int sc = (lane % C4) * 4;    // column within the wave's slab
-    const int ncol = n0 + wn * NT * 32 + sc;
-    const bool split_out = p.splits > 1;
-    const bool vec = split_out || ((d.ldo & 3) == 0 && (d.N & 3) == 0 &&
-                                   ((reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.res)) & 15) == 0 &&
-                                   ((d.stride_o & 3) == 0));
-    float* outp = split_out ? d.ws + ((int64_t)z * p.splits + split) * (int64_t)p.M * d.N
-                            : d.out + (int64_t)z * d.stride_o;
-    const float* resp = (!split_out && d.res) ? d.res + (int64_t)z * d.stride_o : nullptr;
-    const bool need_b = !split_out && (d.rowbias != nullptr || d.out_mul > 0);
-    const int ld_out = split_out ? d.N : d.ldo;
-    if constexpr (NT == 2) {
-        if (d.epi_mode == ALDM_EPI_GEGLU) {
-            // fused GEGLU (attention.py:42-44): the wave's slab holds 32 value columns then their 32
-            // gate columns; 8 lanes cover a row's 32 outputs, one wave-wide read covers 8 rows.
-            const int gr = lane >> 3, gc = (lane & 7) * 4;
-            const int ncol_p = n0 + wn * 64 + gc;              // packed column of the value quad
-            const int ncol_o = ((n0 + wn * 64) >> 1) + gc;     // output column
-            const bool cok = ncol_p < d.N;  // N % 64 == 0: a wave's 64-column slab is all in or all out
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-            if (d.bias && cok) {
-                bv = *reinterpret_cast<const f32x4*>(d.bias + ncol_p);
-                bg = *reinterpret_cast<const f32x4*>(d.bias + ncol_p + 32);
-            }
-            float* go = d.out + (int64_t)z * d.stride_o;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][e];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int r = it * 8 + gr;
-                    f32x4 xv = *reinterpret_cast<const f32x4*>(&stg[r * SP + gc]) + bv;
-                    const f32x4 xg = *reinterpret_cast<const f32x4*>(&stg[r * SP + 32 + gc]) + bg;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[c] *= act_apply(xg[c], ALDM_ACT_GELU, 0.f);
-                    const int m = m0 + (wm * MT + i) * 32 + r;
-                    if (m < p.M && cok) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;
-                }
-            }
-            return;
-        }
-    }
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (!split_out && d.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bias4[c] = d.bias[min(ncol + c, d.N - 1)];
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        // registers -> LDS (wave private, conflict free: 32 consecutive columns per half wave)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][e];
-        // LDS -> float4 per lane, ITC wave-wide reads at a time (bounds the live registers)
-#pragma unroll
-        for (int itc = 0; itc < IT; itc += ITC) {
-        f32x4 v[ITC];
-        int64_t rowoff[ITC];
-        int rboff[ITC];
-        unsigned okmask = 0;
-#pragma unroll
-        for (int it = 0; it < ITC; ++it) {
-            const int r = (itc + it) * RPI + sr;
-            v[it] = *reinterpret_cast<const f32x4*>(&stg[r * SP + sc]);
-            const int m = m0 + (wm * MT + i) * 32 + r;
-            bool ok = m < p.M && ncol < d.N;
-            int b = 0;
-            int64_t orow = m;
-            if (need_b) {
-                b = m / p.OHW;
-                if (d.out_mul > 0) {
-                    const int qq = m - b * p.OHW;
-                    const int t = qq * d.out_mul + d.out_off;
-                    ok = ok && (unsigned)t < (unsigned)d.out_len;
-                    orow = (int64_t)b * d.out_len + t;
-                }
-            }
-            rowoff[it] = ok ? orow * ld_out + ncol : 0;
-            rboff[it] = ok ? b * p.rb_ld + ncol : 0;
-            okmask |= (ok ? 1u : 0u) << it;
-        }
-        if (split_out) {
-#pragma unroll
-            for (int it = 0; it < ITC; ++it)
-                if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
-            continue;
-        }
-#pragma unroll
-        for (int it = 0; it < ITC; ++it) v[it] += bias4;
-        if (d.rowbias) {
-#pragma unroll
-            for (int it = 0; it < ITC; ++it)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[it][c] += d.rowbias[rboff[it] + (ncol + c < d.N ? c : 0)];
-        }
-        switch (d.act) {
-            case ALDM_ACT_NONE: break;
-            case ALDM_ACT_SILU:
-#pragma unroll
-                for (int it = 0; it < ITC; ++it)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], ALDM_ACT_SILU, 0.f);
-                break;
-            case ALDM_ACT_GELU:
-#pragma unroll
-                for (int it = 0; it < ITC; ++it)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], ALDM_ACT_GELU, 0.f);
-                break;
-            default:
-#pragma unroll
-                for (int it = 0; it < ITC; ++it)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[it][c] = act_apply(v[it][c], d.act, d.act_slope);
-                break;
-        }
-        if (vec) {
-            if (resp) {
-#pragma unroll
-                for (int it = 0; it < ITC; ++it) v[it] += *reinterpret_cast<const f32x4*>(resp + rowoff[it]);
-            }
-#pragma unroll
-            for (int it = 0; it < ITC; ++it) v[it] *= d.alpha;
-            if (d.accumulate) {
-#pragma unroll
-                for (int it = 0; it < ITC; ++it) v[it] += *reinterpret_cast<const f32x4*>(outp + rowoff[it]);
-            }
-#pragma unroll
-            for (int it = 0; it < ITC; ++it)
-                if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
-        } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
-#pragma unroll
-            for (int it = 0; it < ITC; ++it)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!((okmask >> it) & 1u) || ncol + c >= d.N) continue;
-                    float x = v[it][c];
-                    if (resp) x += resp[rowoff[it] + c];
-                    x *= d.alpha;
-                    if (d.accumulate) x += outp[rowoff[it] + c];
-                    outp[rowoff[it] + c] = x;
-                }
-        }
-        }  // itc
-    }
+    igemm_epilogue<MT, NT>(p, acc, reinterpret_cast<float*>(&smem[0]), m0, n0, wave, wm, wn, lane, z, split);
 }
 
 }  // namespace aldm

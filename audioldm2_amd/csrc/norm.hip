@@ -1,7 +1,7 @@
 // norm.hip — GroupNorm statistics (-> per-(sample, channel) affine consumed by the igemm prologue),
 // LayerNorm, row softmax.  All HBM-bound: one coalesced 16-byte read per element, fp32 math,
 // deterministic reduction order (no atomics).
-#include "common.h"
+#include "igemm_epilogue.h"
 
 namespace aldm {
 
@@ -15,6 +15,24 @@ namespace aldm {
 //         scale[b,c] = rstd*gamma[c], shift[b,c] = beta[c] - mean*rstd*gamma[c].
 constexpr int GN_ITERS = 16;
 constexpr int GN_UNROLL = 8;  // pixel loads in flight per thread
+
+// Numerics: E[x^2] - E[x]^2 over raw fp32 sums loses the variance as soon as |mean| >> std (a trained checkpoint's
+// post-conv activations; ATen's GroupNorm is Welford).  Here every thread accumulates sum / sum of squares of
+// (x - pivot) with pivot = the first value it sees (same group, so x - pivot is of the order of the group's spread),
+// turns them into (n, mean, M2 = sum (x - mean)^2) and partials are merged with Chan's parallel-variance formula in
+// fp64, in a fixed order (deterministic, no atomics): M2 = sum M2_t + sum n_t (mean_t - mean)^2.
+struct GnPart {
+    float n, mean, m2;
+};
+
+__device__ __forceinline__ void gn_merge(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+    if (nb <= 0.0) return;
+    const double nt = n + nb;
+    const double dlt = mb - mean;
+    mean += dlt * (nb / nt);
+    m2 += m2b + dlt * dlt * (n * nb / nt);
+    n = nt;
+}
 
 // FUSED: one block covers a whole (small) sample, keeps the group sums in LDS and finalises in the
 // same launch — for the deep UNet levels (P <= 256 pixels) the two-launch form is pure latency.
@@ -35,20 +53,16 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     const int p1 = min(P, p0 + chunk_px);
     const int tid = threadIdx.x;
     const int tx = tid % cols, ty = tid / cols;
-    __shared__ float ps[256][2];
+    __shared__ GnPart ps[256];
     // columns handled in passes of `cols` (cols = min(C4, 256))
     const int npass = (C4 + cols - 1) / cols;
-    __shared__ float gsum[64][2];
-    if (FUSED) {
-        if (tid < 64) gsum[tid][0] = gsum[tid][1] = 0.f;
-    } else {
-        for (int g = tid; g < 2 * G; g += 256) ws[((int64_t)(b * gridDim.x + chunk) * G) * 2 + g] = 0.f;
-    }
+    __shared__ double gacc[64][3];   // running (n, mean, M2) per group of this block
+    if (tid < 64) gacc[tid][0] = gacc[tid][1] = gacc[tid][2] = 0.0;
     __syncthreads();
     for (int cp = 0; cp < npass; ++cp) {
         const int c4 = cp * cols + tx;
-        float s = 0.f, ss = 0.f;
-        if (ty < rows && c4 < C4) {
+        GnPart part = {0.f, 0.f, 0.f};
+        if (ty < rows && c4 < C4 && p0 + ty < p1) {
             const int c = c4 << 2;
             const bool first = c < C1;
             const float* src = first ? x1 + (int64_t)b * P * C1 + c : x2 + (int64_t)b * P * C2 + (c - C1);
@@ -60,73 +74,82 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 #pragma unroll
             for (int u = 0; u < GN_UNROLL; ++u) sa[u] = sq[u] = 0.f;
             int p = p0 + ty;
+            const float pivot = src[(int64_t)p * pitch];
+            int cnt = 0;
             for (; p + (GN_UNROLL - 1) * rows < p1; p += GN_UNROLL * rows) {
                 f32x4 v[GN_UNROLL];
 #pragma unroll
                 for (int u = 0; u < GN_UNROLL; ++u)
-                    v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + u * rows) * pitch);
+                    v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(p + u * rows) * pitch) - pivot;
 #pragma unroll
                 for (int u = 0; u < GN_UNROLL; ++u) {
                     sa[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
                     sq[u] += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
                 }
+                cnt += GN_UNROLL;
             }
             for (; p < p1; p += rows) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)p * pitch);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)p * pitch) - pivot;
                 sa[0] += (v[0] + v[1]) + (v[2] + v[3]);
                 sq[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                ++cnt;
             }
+            float s = 0.f, ss = 0.f;
 #pragma unroll
             for (int u = 0; u < GN_UNROLL; u += 2) {
                 s += sa[u] + sa[u + 1];
                 ss += sq[u] + sq[u + 1];
             }
+            const float n = 4.0f * (float)cnt;
+            const float md = s / n;   // mean of (x - pivot)
+            part.n = n;
+            part.mean = pivot + md;
+            part.m2 = fmaxf(ss - s * md, 0.f);
         }
-        ps[tid][0] = s;
-        ps[tid][1] = ss;
+        ps[tid] = part;
         __syncthreads();
         // groups touched by this column pass: c4 in [cp*cols, cp*cols+cols)
-        // one thread per (group) sums, in fixed order, all (tx, ty) of that group.
+        // one thread per group merges, in fixed order, all (tx, ty) of that group.
         if (tid < G) {
             const int g = tid;
             const int lo = max(g * Cg4, cp * cols), hi = min((g + 1) * Cg4, min(C4, (cp + 1) * cols));
             if (lo < hi) {
-                float a = 0.f, a2 = 0.f;
+                double n = gacc[g][0], mean = gacc[g][1], m2 = gacc[g][2];
                 for (int yy = 0; yy < rows; ++yy)
                     for (int cc = lo; cc < hi; ++cc) {
-                        const int t = yy * cols + (cc - cp * cols);
-                        a += ps[t][0];
-                        a2 += ps[t][1];
+                        const GnPart& t = ps[yy * cols + (cc - cp * cols)];
+                        gn_merge(n, mean, m2, (double)t.n, (double)t.mean, (double)t.m2);
                     }
-                if (FUSED) {
-                    gsum[g][0] += a;
-                    gsum[g][1] += a2;
-                } else {
-                    float* w = ws + ((int64_t)(b * gridDim.x + chunk) * G + g) * 2;
-                    w[0] += a;
-                    w[1] += a2;
-                }
+                gacc[g][0] = n;
+                gacc[g][1] = mean;
+                gacc[g][2] = m2;
             }
         }
         __syncthreads();
     }
     if (FUSED) {
         const int Cg = C / G;
+        __shared__ float fin[64][2];
         if (tid < G) {
-            const double n = (double)P * Cg;
-            const double mean = (double)gsum[tid][0] / n;
-            double var = (double)gsum[tid][1] / n - mean * mean;
+            const double n = gacc[tid][0];
+            double var = n > 0.0 ? gacc[tid][2] / n : 0.0;
             if (var < 0.0) var = 0.0;
-            gsum[tid][0] = (float)mean;
-            gsum[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
+            fin[tid][0] = (float)gacc[tid][1];
+            fin[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
         }
         __syncthreads();
         for (int c = tid; c < C; c += 256) {
             const int g = c / Cg;
-            const float sc = gsum[g][1] * (gamma ? gamma[c] : 1.f);
+            const float sc = fin[g][1] * (gamma ? gamma[c] : 1.f);
             scale[(int64_t)b * C + c] = sc;
-            shift[(int64_t)b * C + c] = (beta ? beta[c] : 0.f) - gsum[g][0] * sc;
+            shift[(int64_t)b * C + c] = (beta ? beta[c] : 0.f) - fin[g][0] * sc;
         }
+    } else if (tid < G) {
+        // fp64 partial of this chunk: {n, mean, M2} (mean needs the full precision: it is the pivot of the merge)
+        double* w = reinterpret_cast<double*>(ws) + ((int64_t)(b * gridDim.x + chunk) * G + tid) * 3;
+        w[0] = gacc[tid][0];
+        w[1] = gacc[tid][1];
+        w[2] = gacc[tid][2];
     }
 }
 
@@ -138,36 +161,32 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift) {
     const int b = blockIdx.x;
     __shared__ float s_mean[64], s_rstd[64];
-    __shared__ double s_part[256][2];
+    __shared__ double s_part[256][3];
     const int Cg = C / G;
+    const double* wsd = reinterpret_cast<const double*>(ws);
     // 256 threads: LPG lanes per group walk that group's chunk partials in a strided, fixed pattern
     // (independent loads in flight instead of one thread chasing `chunks` dependent loads), then a
     // fixed-order LDS combine -> deterministic.
     const int LPG = 256 / G >= 1 ? 256 / G : 1;  // G <= 64 -> LPG >= 4
     {
         const int g = threadIdx.x / LPG, l = threadIdx.x % LPG;
-        double s = 0.0, ss = 0.0;
+        double n = 0.0, mean = 0.0, m2 = 0.0;
         if (g < G) {
             for (int ch = l; ch < chunks; ch += LPG) {
-                const float* w = ws + ((int64_t)(b * chunks + ch) * G + g) * 2;
-                s += (double)w[0];
-                ss += (double)w[1];
+                const double* w = wsd + ((int64_t)(b * chunks + ch) * G + g) * 3;
+                gn_merge(n, mean, m2, w[0], w[1], w[2]);
             }
         }
-        s_part[threadIdx.x][0] = s;
-        s_part[threadIdx.x][1] = ss;
+        s_part[threadIdx.x][0] = n;
+        s_part[threadIdx.x][1] = mean;
+        s_part[threadIdx.x][2] = m2;
     }
     __syncthreads();
     if (threadIdx.x < G) {
         const int g = threadIdx.x;
-        double s = 0.0, ss = 0.0;
-        for (int l = 0; l < LPG; ++l) {
-            s += s_part[g * LPG + l][0];
-            ss += s_part[g * LPG + l][1];
-        }
-        const double n = (double)P * Cg;
-        const double mean = s / n;
-        double var = ss / n - mean * mean;
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (int l = 0; l < LPG; ++l) gn_merge(n, mean, m2, s_part[g * LPG + l][0], s_part[g * LPG + l][1], s_part[g * LPG + l][2]);
+        double var = n > 0.0 ? m2 / n : 0.0;
         if (var < 0.0) var = 0.0;
         s_mean[g] = (float)mean;
         s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
@@ -193,7 +212,8 @@ template <int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         float* __restrict__ y, int M, int C,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps) {
+                                                        const float* __restrict__ beta, float eps,
+                                                        void* __restrict__ y_split) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
@@ -242,11 +262,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (row0 + r >= M) break;
-        float* yr = y + (int64_t)(row0 + r) * C;
+        float* yr = y ? y + (int64_t)(row0 + r) * C : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lane + 64 * i;
-            if (c4 < C4) *reinterpret_cast<f32x4*>(yr + 4 * c4) = (v[r][i] - mean[r]) * rstd[r] * ga[i] + be[i];
+            if (c4 < C4) {
+                const f32x4 o = (v[r][i] - mean[r]) * rstd[r] * ga[i] + be[i];
+                if (yr) *reinterpret_cast<f32x4*>(yr + 4 * c4) = o;
+                if (y_split) split_store4(y_split, row0 + r, C, 4 * c4, o);   // the next GEMM's pre-split A operand
+            }
         }
     }
 }
@@ -317,7 +341,7 @@ using namespace aldm;
 extern "C" int64_t aldm_gn_ws_floats(int B, int P, int C, int G) {
     int cols, rows, chunk_px, chunks;
     gn_geometry(P, C, &cols, &rows, &chunk_px, &chunks);
-    return (int64_t)B * chunks * G * 2;
+    return (int64_t)B * chunks * G * 6 + 2;   // {n, mean, M2} in fp64 per (sample, chunk, group), 8-byte aligned
 }
 
 extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1, int C2,
@@ -326,6 +350,7 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
     if (!x2) C2 = 0;
     const int C = C1 + C2;
     ALDM_CHECK(x1 && scale && shift && ws, "aldm_groupnorm_stats: null pointer");
+    ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~uintptr_t(7));   // fp64 partials
     ALDM_CHECK(G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && C1 % 4 == 0,
                "aldm_groupnorm_stats: need C%%G==0, (C/G)%%4==0, C1%%4==0 (C1=%d C2=%d G=%d)", C1, C2, G);
     int cols, rows, chunk_px, chunks;
@@ -344,23 +369,34 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
     return 0;
 }
 
-extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
-                              const float* beta, float eps, void* stream) {
-    ALDM_CHECK(x && y && gamma && beta, "aldm_layernorm: null pointer");
-    ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "aldm_layernorm: C=%d must be a multiple of 4 and <= %d",
-               C, 256 * LN_MAXV);
+static int layernorm_launch(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
+                            const float* beta, float eps, void* stream, const char* name) {
+    ALDM_CHECK(x && (y || y_split) && gamma && beta, "%s: null pointer", name);
+    ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "%s: C=%d must be a multiple of 4 and <= %d", name, C, 256 * LN_MAXV);
+    ALDM_CHECK(y_split == nullptr || (C % 32 == 0 && (reinterpret_cast<uintptr_t>(y_split) & 15) == 0),
+               "%s: a split-image output needs C %% 32 == 0 and 16-byte alignment", name);
     hipStream_t st = (hipStream_t)stream;
 #define ALDM_LN(V_, R_)                                                                                  \
     hipLaunchKernelGGL((layernorm_kernel<V_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, C, \
-                       gamma, beta, eps)
+                       gamma, beta, eps, y_split)
     const int nv = cdiv(C / 4, 64);
     if (nv <= 1) ALDM_LN(1, 4);
     else if (nv <= 2) ALDM_LN(2, 4);
     else if (nv <= 4) ALDM_LN(4, 2);
     else ALDM_LN(8, 1);
 #undef ALDM_LN
-    ALDM_LAUNCH_CHECK("aldm_layernorm");
+    ALDM_LAUNCH_CHECK(name);
     return 0;
+}
+
+extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
+                              const float* beta, float eps, void* stream) {
+    return layernorm_launch(x, y, nullptr, M, C, gamma, beta, eps, stream, "aldm_layernorm");
+}
+
+extern "C" int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
+                                    const float* beta, float eps, void* stream) {
+    return layernorm_launch(x, y, y_split, M, C, gamma, beta, eps, stream, "aldm_layernorm_split");
 }
 
 extern "C" int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale,

@@ -98,6 +98,13 @@ class _NoiseFeed:
         self.pin = [torch.empty((chunk,) + tuple(shape)).pin_memory() for _ in range(nbuf)]
         self.qpin = [torch.empty((chunk,) + tuple(shape)).pin_memory() for _ in range(nbuf)] if with_mask else None
         self.stream = torch.cuda.Stream(device=dev)
+        # the device buffers were just allocated on the current stream: the caching allocator may hand out a block that
+        # kernels already queued there (the previous run's noise copies) still read, so the upload stream must not
+        # start writing before the current stream has reached this point
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.noise.record_stream(self.stream)
+        if self.qnoise is not None:
+            self.qnoise.record_stream(self.stream)
         self.events = {}
         self.produced = 0  # chunks drawn so far
 
@@ -277,13 +284,17 @@ class DDIMSampler(object):
             key = (tuple(shape), tuple(tuple(c.shape) for c in prepared["ctxs"]),
                    None if prepared["y"] is None else tuple(prepared["y"].shape))
         ent = unet._graph_cache.get(key) if can_cache else None
+        if ent is not None and ent.get("kv") is None:
+            # the entry never got as far as recording the K/V buffers its graph reads (e.g. an interrupted first run)
+            unet._graph_cache.pop(key, None)
+            ent = None
         if ent is not None:
             for dst, src in zip(ent["prepared"]["ctxs"] + ent["prepared"]["masks"],
                                 prepared["ctxs"] + prepared["masks"]):
                 dst.copy_(src)
             if prepared["y"] is not None:
                 ent["prepared"]["y"].copy_(prepared["y"])
-            unet.refresh_context_kv(ent["prepared"]["ctxs"])
+            unet.refresh_context_kv(ent["kv"])  # in place: the captured graph keeps reading these buffers
             ent["x_cur"].copy_(img)
         else:
             # static buffers = the graph's inputs
@@ -324,6 +335,10 @@ class DDIMSampler(object):
                 # img = q_sample(x0, ts)*mask + (1-mask)*img   (ddim.py:226-231, ddpm.py:430-436)
                 ops.inpaint_blend(x_cur, x0_d, qn[i], mask_d, blend_coef[i])
             run_step()  # eager the first time, then one HIP-graph replay per step
+            if can_cache and ent.get("kv") is None:
+                # after the eager first step: the K/V projections of this run's contexts exist; the cache entry owns
+                # them from here on (the graph captured at the next step reads these very buffers)
+                ent["kv"] = unet.collect_context_kv(ent["prepared"]["ctxs"])
             if opens_chunk:
                 feed.produce_next()  # draw + upload the NEXT chunk while the GPU works on this one
             if callback:

@@ -70,12 +70,15 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_byte
         total += flat.numel() * flat.element_size()
         bucket, size = [], 0
 
+    last = None
     for t in tensors:
         if not t.is_floating_point():
             continue
         nbytes = t.numel() * t.element_size()
-        if size + nbytes > bucket_bytes and bucket:
+        kind = (t.device, t.dtype)   # a flat bucket holds one device and one dtype (no silent promotion)
+        if bucket and (size + nbytes > bucket_bytes or kind != last):
             flush()
+        last = kind
         bucket.append(t.data)
         size += nbytes
     flush()
@@ -87,8 +90,15 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> int:
     packed-weight caches so the kernels re-pack from the received values."""
     sent = broadcast_tensors(list(module.parameters()) + list(module.buffers()), src=src)
     for m in module.modules():
+        # everything derived from the old values goes: packed weights, cached context K/V projections, captured graphs
+        if hasattr(m, "invalidate_packed"):
+            m.invalidate_packed()
         if hasattr(m, "_pk"):
             m._pk = None
+        if hasattr(m, "_kv"):
+            m._kv = None
+        if hasattr(m, "_graph_cache"):
+            m._graph_cache = {}
     return sent
 
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALDM_LIB_PATH") or os.path.join(_HERE, "libaldm_hip.so")  # override: debug builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU, ACT_GELU_TANH = range(7)
 B_PACKED, B_NT = 0, 1
@@ -44,7 +44,8 @@ class IgemmDesc(C.Structure):
         ("rowbias_ld", C.c_int32), ("epi_mode", C.c_int32),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("hint_bm", C.c_int32), ("hint_bn", C.c_int32), ("hint_splits", C.c_int32), ("hint_kgroups", C.c_int32),
-        ("w_split", C.c_void_p), ("hint_mma", C.c_int32), ("reserved0", C.c_int32),
+        ("w_split", C.c_void_p), ("hint_mma", C.c_int32), ("hint_stages", C.c_int32),
+        ("a_split", C.c_void_p), ("out_split", C.c_void_p), ("out_split_c", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -57,7 +58,16 @@ _SIGS = {
                                   C.POINTER(C.c_int)]),
     "aldm_igemm_ws_floats": (C.c_int64, [C.POINTER(IgemmDesc)]),
     "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aldm_igemm_force_stages": (None, [C.c_int]),
     "aldm_igemm_wave8_mask": (C.c_int, [C.c_int]),
+    "aldm_split_image_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "aldm_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "aldm_layernorm_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_float, C.c_void_p]),
+    "aldm_attention_d32_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_float, C.c_void_p]),
     "aldm_igemm_mma": (C.c_int, [C.c_int]),
     "aldm_split_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "aldm_pack_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

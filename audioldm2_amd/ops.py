@@ -80,6 +80,95 @@ class Packed:
         return self.split.data_ptr()
 
 
+class SplitT:
+    """A split image (include/aldm_hip.h "split images"): the exact 3-way bf16 split of a channels-last fp32 tensor of
+    logical shape `shape` = [..., C], stored [rows, C/32, 3, 32] as int16 — the pre-split A operand of the DMA-fed GEMM."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data: torch.Tensor, shape):
+        self.data = data
+        self.shape = tuple(shape)
+
+    @staticmethod
+    def empty(shape, device) -> "SplitT":
+        C_ = shape[-1]
+        assert C_ % 32 == 0, f"split image needs C % 32 == 0, got {C_}"
+        rows = 1
+        for s_ in shape[:-1]:
+            rows *= s_
+        return SplitT(torch.empty((rows, C_ // 32, 3, 32), device=device, dtype=torch.int16), shape)
+
+    @property
+    def C(self) -> int:
+        return self.shape[-1]
+
+    @property
+    def rows(self) -> int:
+        return self.data.shape[0]
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+    def view(self, *shape) -> "SplitT":
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        n = 1
+        for s_ in shape:
+            n *= abs(s_)
+        tot = self.rows * self.C
+        shape = tuple(tot // n if s_ == -1 else s_ for s_ in shape)
+        assert shape[-1] == self.C, "a split image can only be re-viewed over its row dimensions"
+        return SplitT(self.data, shape)
+
+    def float(self) -> torch.Tensor:
+        """hi + mid + lo back to fp32 (tests / debugging): exact."""
+        parts = (self.data.to(torch.int32) << 16).view(torch.float32)
+        return (parts[:, :, 0] + parts[:, :, 1] + parts[:, :, 2]).reshape(self.shape)
+
+
+# DMA-fed GEMM path (pre-split activations, csrc/igemm_dma.h): on by default in "bf16x6" mode; ALDM_DMA=0 / set_dma(False)
+# keep every activation fp32 and split A inside the K loop (the round-1 kernels).
+DMA_MODE = os.environ.get("ALDM_DMA", "1") != "0"
+
+
+def set_dma(on: bool) -> bool:
+    global DMA_MODE
+    prev, DMA_MODE = DMA_MODE, bool(on)
+    return prev
+
+
+def use_dma() -> bool:
+    return DMA_MODE and MMA_MODE == "bf16x6"
+
+
+def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act: int = ACT_NONE,
+               want_raw: bool = False):
+    """split(act(x*scale + shift)) of channels-last x (++ x2 along C) -> SplitT; pre = (scale, shift) each [B, C]
+    (GroupNorm apply, from gn_stats).  want_raw: also return split(x ++ x2)."""
+    _chk(x, "split_rows.x")
+    C1 = x.shape[-1]
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "split_rows.x2")
+        assert x2.shape[:-1] == x.shape[:-1]
+        C2 = x2.shape[-1]
+    shape = (*x.shape[:-1], C1 + C2)
+    rows = x.numel() // C1
+    P = rows // x.shape[0]
+    dst = SplitT.empty(shape, x.device)
+    raw = SplitT.empty(shape, x.device) if want_raw else None
+    sc = sh = None
+    if pre is not None:
+        sc, sh = pre
+        assert sc.shape == (x.shape[0], C1 + C2) and sc.is_contiguous() and sh.is_contiguous()
+    _l.check(_l.load().aldm_split_rows(x.data_ptr(), _p(x2), C1, C2, rows, P, _p(sc), _p(sh), act, dst.data_ptr(),
+                                       None if raw is None else raw.data_ptr(), _stream()), "split_rows")
+    return (dst, raw) if want_raw else dst
+
+
 # Optional profiling hook (bench.py's roofline leg): when PROFILE is a list, every igemm launch is
 # bracketed by events on the launch stream and recorded as (what, BM, BN, flops, ev_start, ev_end,
 # (M, N, K, taps, C2, has_pre, pre_act, batch, splits)).
@@ -126,17 +215,19 @@ def tune_key(d: IgemmDesc) -> str:
     return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}"
 
 
-def _tuned_table(bx: bool = False):
-    """{geometry key: [BM, BN, splits, kgroups(, mma)]} for the fp32-MFMA (bx=False) or bf16-split launches."""
+def _tuned_table(bx=False):
+    """{geometry key: [BM, BN, splits, kgroups(, mma)]} for the fp32-MFMA (bx=False) or bf16-split (True) launches;
+    bx="dma": {key: [BM, BN, splits, stages]} for the DMA-fed kernel."""
     global _TUNED
     if _TUNED is None:
-        _TUNED = {False: {}, True: {}}
+        _TUNED = {False: {}, True: {}, "dma": {}}
         if os.environ.get("ALDM_NO_TUNING", "0") != "1":
-            for mode, name in ((False, "mi355x_igemm.json"), (True, "mi355x_igemm_bf16x6.json")):
+            for mode, name in ((False, "mi355x_igemm.json"), (True, "mi355x_igemm_bf16x6.json"),
+                               ("dma", "mi355x_igemm_dma.json")):
                 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", name)
                 if os.path.exists(path):
                     with open(path) as f:
-                        _TUNED[mode] = {k: v[:5] if mode else v[:4] for k, v in json.load(f)["entries"].items()}
+                        _TUNED[mode] = {k: v[:5] if mode is True else v[:4] for k, v in json.load(f)["entries"].items()}
     return _TUNED[bx]
 
 
@@ -145,10 +236,15 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     key = tune_key(d)
     if TUNE_LOG is not None:
         TUNE_LOG.append(key)
-    hint = _tuned_table(bool(d.w_split)).get(key)
-    if hint is not None:
-        d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = hint[:4]
-        d.hint_mma = hint[4] if len(hint) > 4 else 0  # bf16x6 table: 1 = this shape is faster on the fp32 MFMA
+    if d.a_split:
+        hint = _tuned_table("dma").get(key)
+        if hint is not None:
+            d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = hint[:4]
+    else:
+        hint = _tuned_table(bool(d.w_split)).get(key)
+        if hint is not None:
+            d.hint_bm, d.hint_bn, d.hint_splits, d.hint_kgroups = hint[:4]
+            d.hint_mma = hint[4] if len(hint) > 4 else 0  # bf16x6 table: 1 = this shape is faster on the fp32 MFMA
     _workspace(lib, d, device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     if PROFILE is None:
         _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
@@ -183,6 +279,8 @@ def _pre_mode(d: IgemmDesc) -> int:
 def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) -> str:
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
+    if d.a_split:
+        return f"igemm_dma_kernel<{bm}, {bn}>"
     pre = _pre_mode(d)
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     # 8 waves per tile: same rule as csrc/igemm.hip (ALDM_IGEMM_W8 tile mask, default 128x128 GroupNorm prologues)
@@ -197,10 +295,11 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     return f"igemm_kernel<{bm}, {bn}, {wm}, {wn}, {pre}, {kg}, {uni}, {'true' if bx else 'false'}>"
 
 
-def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0) -> None:
-    """Tuning override for tools/tests: force tile / split-K / wave groups of subsequent igemm launches
-    (bm = 0: automatic)."""
+def igemm_force(bm: int = 0, bn: int = 0, splits: int = 0, kgroups: int = 0, stages: int = 0) -> None:
+    """Tuning override for tools/tests: force tile / split-K / wave groups (/ LDS ring depth of the DMA-fed kernel) of
+    subsequent igemm launches (bm = 0: automatic)."""
     _l.load().aldm_igemm_force(bm, bn, splits, kgroups)
+    _l.load().aldm_igemm_force_stages(stages)
 
 
 def attention_mma(mode: int) -> int:
@@ -262,23 +361,34 @@ def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
     return pack_conv(weight.detach()[perm], None if bias is None else bias.detach()[perm])
 
 
-def linear_geglu(x: torch.Tensor, pw: Packed) -> torch.Tensor:
+def linear_geglu(x, pw: Packed, split_out: Optional[str] = None):
     """y = value * gelu_erf(gate) with [value | gate] = x @ W^T + b fused into the GEMM epilogue
-    (attention.py:37-45); pw from pack_geglu.  x: [..., Cin] -> [..., N/2]."""
-    _chk(x, "linear_geglu.x")
+    (attention.py:37-45); pw from pack_geglu.  x: [..., Cin] fp32 or SplitT -> [..., N/2] (split_out: None -> fp32,
+    "only" -> SplitT, "also" -> (fp32, SplitT))."""
+    is_split = isinstance(x, SplitT)
+    if not is_split:
+        _chk(x, "linear_geglu.x")
     shp = x.shape
-    M = x.numel() // shp[-1]
+    M = (x.rows if is_split else x.numel() // shp[-1])
     assert shp[-1] == pw.Cin and pw.KH == 1 and pw.KW == 1 and pw.N % 64 == 0
-    out = torch.empty((*shp[:-1], pw.N // 2), device=x.device, dtype=torch.float32)
+    oshape = (*shp[:-1], pw.N // 2)
+    out = None if split_out == "only" else torch.empty(oshape, device=x.device, dtype=torch.float32)
+    so = SplitT.empty(oshape, x.device) if split_out else None
     d = IgemmDesc()
-    d.x1 = x.data_ptr(); d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
+    if is_split:
+        d.a_split = x.data_ptr()
+    else:
+        d.x1 = x.data_ptr()
+    d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N; d.w_split = pw.split_ptr()
-    d.bias = _p(pw.bias); d.out = out.data_ptr(); d.ldo = pw.N // 2; d.alpha = 1.0
+    d.bias = _p(pw.bias); d.out = _p(out); d.ldo = pw.N // 2; d.alpha = 1.0
+    if so is not None:
+        d.out_split = so.data_ptr(); d.out_split_c = pw.N // 2
     d.epi_mode = _l.EPI_GEGLU; d.batch = 1
     _igemm(d, "igemm(geglu)")
-    return out
+    return so if split_out == "only" else ((out, so) if split_out else out)
 
 
 def pack_convtr1d(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int) -> List[Packed]:
@@ -305,10 +415,16 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
          act: int = ACT_NONE, act_slope: float = 0.0, alpha: float = 1.0,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
          remap: Optional[Tuple[int, int, int]] = None,
-         use_pw_bias: bool = True) -> torch.Tensor:
+         use_pw_bias: bool = True, split_out: Optional[str] = None):
     """Implicit-GEMM convolution (aldm_igemm).  x: [B, H, W, C1] (+ x2: [B, H, W, C2] concatenated
-    along C).  Returns [B, OH, OW, N] (or the remapped [B, 1, out_len, N])."""
-    _chk(x, "conv.x")
+    along C), or a SplitT of that shape (pre-split operand -> DMA-fed kernel; no x2 / pre then).  Returns
+    [B, OH, OW, N] (or the remapped [B, 1, out_len, N]); split_out = "only": a SplitT of the result instead,
+    "also": (fp32, SplitT)."""
+    is_split = isinstance(x, SplitT)
+    if is_split:
+        assert x2 is None and pre is None and pre_act == ACT_NONE, "a pre-split operand takes no prologue"
+    else:
+        _chk(x, "conv.x")
     B, H, W, C1 = x.shape
     C2 = 0
     if x2 is not None:
@@ -329,16 +445,23 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     else:
         out_mul = out_off = out_len = 0
         oshape = (B, OH, OW, N)
-    if out is None:
+    if split_out == "only":
+        assert out is None and not accumulate
+    elif out is None:
         assert not accumulate
         out = torch.empty(oshape, device=x.device, dtype=torch.float32)
     else:
         _chk(out, "conv.out")
         assert out.numel() == oshape[0] * oshape[1] * oshape[2] * oshape[3], (out.shape, oshape)
+    so = SplitT.empty(oshape, x.device) if split_out else None
     if bias is None and use_pw_bias:
         bias = pw.bias
     d = IgemmDesc()
-    d.x1 = x.data_ptr(); d.x2 = _p(x2)
+    if is_split:
+        d.a_split = x.data_ptr()
+    else:
+        d.x1 = x.data_ptr()
+    d.x2 = _p(x2)
     d.C1 = C1; d.C2 = C2; d.pix1 = 0; d.pix2 = 0
     d.B = B; d.H = H; d.W = W; d.up_h = up[0]; d.up_w = up[1]
     d.KH = pw.KH; d.KW = pw.KW; d.SH = stride[0]; d.SW = stride[1]
@@ -349,7 +472,9 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.pre_act = pre_act; d.pre_slope = pre_slope
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0; d.w_split = pw.split_ptr()
     d.K = pw.K; d.N = N
-    d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = out.data_ptr()
+    d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = _p(out)
+    if so is not None:
+        d.out_split = so.data_ptr(); d.out_split_c = N
     if rowbias is not None:
         if not (rowbias.dim() == 2 and rowbias.stride(1) == 1 and rowbias.shape == (B, N)):
             raise RuntimeError("conv.rowbias: need a [B, N] fp32 view with unit inner stride")
@@ -359,15 +484,24 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.out_mul = out_mul; d.out_off = out_off; d.out_len = out_len
     d.batch = 1
     _igemm(d, "igemm(conv)")
-    return out.view(oshape)
+    if split_out == "only":
+        return so
+    return (out.view(oshape), so) if split_out else out.view(oshape)
 
 
-def linear(x: torch.Tensor, pw: Packed, **kw) -> torch.Tensor:
-    """x: [..., Cin] -> [..., N] through the same engine (1x1 'conv' over M rows)."""
+def linear(x, pw: Packed, **kw):
+    """x: [..., Cin] (fp32 tensor or SplitT) -> [..., N] through the same engine (1x1 'conv' over M rows)."""
     shp = x.shape
-    M = x.numel() // shp[-1]
-    y = conv(x.reshape(1, 1, M, shp[-1]), pw, **kw)
-    return y.view(*shp[:-1], pw.N)
+    if isinstance(x, SplitT):
+        M = x.rows
+        y = conv(x.view(1, 1, M, shp[-1]), pw, **kw)
+    else:
+        M = x.numel() // shp[-1]
+        y = conv(x.reshape(1, 1, M, shp[-1]), pw, **kw)
+    oshape = (*shp[:-1], pw.N)
+    if isinstance(y, tuple):
+        return y[0].view(oshape), y[1].view(oshape)
+    return y.view(oshape)
 
 
 def _view3(t: torch.Tensor, name: str):
@@ -453,14 +587,22 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups
     return ss[0], ss[1]
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              split_out: Optional[str] = None):
+    """LayerNorm over the last dim; split_out = "only": the result as a SplitT (the next GEMM's pre-split operand),
+    "also": (fp32, SplitT)."""
     _chk(x, "ln.x")
     Cc = x.shape[-1]
     M = x.numel() // Cc
-    y = torch.empty_like(x)
-    _l.check(_l.load().aldm_layernorm(x.data_ptr(), y.data_ptr(), M, Cc, gamma.data_ptr(),
-                                      beta.data_ptr(), eps, _stream()), "layernorm")
-    return y
+    y = None if split_out == "only" else torch.empty_like(x)
+    if not split_out:
+        _l.check(_l.load().aldm_layernorm(x.data_ptr(), y.data_ptr(), M, Cc, gamma.data_ptr(),
+                                          beta.data_ptr(), eps, _stream()), "layernorm")
+        return y
+    so = SplitT.empty(x.shape, x.device)
+    _l.check(_l.load().aldm_layernorm_split(x.data_ptr(), _p(y), so.data_ptr(), M, Cc, gamma.data_ptr(),
+                                            beta.data_ptr(), eps, _stream()), "layernorm_split")
+    return so if split_out == "only" else (y, so)
 
 
 def _rowview(t: torch.Tensor, name: str):
@@ -472,8 +614,10 @@ def _rowview(t: torch.Tensor, name: str):
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *,
-              mask: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
-    """softmax(scale * q k^T [mask]) v per head, head dim 32.  q: [B, Lq, heads*32] views."""
+              mask: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+              split_out: Optional[str] = None):
+    """softmax(scale * q k^T [mask]) v per head, head dim 32.  q: [B, Lq, heads*32] views.  split_out = "only": the
+    result as a SplitT (pre-split operand of the out projection), "also": (fp32, SplitT)."""
     qp, Lq, ldq = _rowview(q, "attn.q")
     kp, Lk, ldk = _rowview(k, "attn.k")
     vp, Lv, ldv = _rowview(v, "attn.v")
@@ -481,12 +625,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *,
     B = q.shape[0]
     if scale is None:
         scale = 32 ** -0.5
-    out = torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
+    out = None if split_out == "only" else torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
     if mask is not None:
         mask = mask.to(torch.float32).reshape(B, Lk).contiguous()
-    _l.check(_l.load().aldm_attention_d32(qp, kp, vp, out.data_ptr(), B, heads, Lq, Lk, ldq, ldk, ldv,
-                                          heads * 32, _p(mask), scale, _stream()), "attention_d32")
-    return out
+    if not split_out:
+        _l.check(_l.load().aldm_attention_d32(qp, kp, vp, out.data_ptr(), B, heads, Lq, Lk, ldq, ldk, ldv,
+                                              heads * 32, _p(mask), scale, _stream()), "attention_d32")
+        return out
+    so = SplitT.empty((B, Lq, heads * 32), q.device)
+    _l.check(_l.load().aldm_attention_d32_split(qp, kp, vp, _p(out), so.data_ptr(), B, heads, Lq, Lk, ldq, ldk, ldv,
+                                                heads * 32, _p(mask), scale, _stream()), "attention_d32_split")
+    return so if split_out == "only" else (out, so)
 
 
 def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:

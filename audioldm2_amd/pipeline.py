@@ -421,7 +421,12 @@ class LatentDiffusion(nn.Module):
             timesteps = self.num_timesteps
         if start_T is not None:
             timesteps = min(timesteps, start_T)
-        draw = lambda: torch.randn(shape)
+        if getattr(self, "noise_shard", None) is None:
+            draw = lambda: torch.randn(shape)
+        else:  # prompt-sharded run: draw the GLOBAL batch like the single-process reference, keep our rows
+            gB, off = self.noise_shard
+            gshape = (gB,) + tuple(shape[1:])
+            draw = lambda: torch.randn(gshape)[off:off + shape[0]].contiguous()
         img_h = draw() if x_T is None else x_T.detach().float().cpu()
         x_cur = img_h.to(dev).contiguous()
         # coefficient rows indexed by t, visited t = timesteps-1 .. 0; no noise at t == 0
@@ -502,6 +507,16 @@ class LatentDiffusion(nn.Module):
         waveform = self.first_stage_model.vocoder.forward_cl(mel.float().contiguous())
         return waveform.cpu().detach().numpy()
 
+    def _check_candidates(self, n_gen):
+        """Fail BEFORE sampling: n_candidate_gen_per_text > 1 ends in CLAP re-ranking (ddpm.py:1554-1568), which
+        needs `self.clap` (a module with cos_similarity(waveform, text)); without it the candidates could only be
+        generated and thrown away."""
+        if n_gen > 1 and self.clap is None:
+            raise NotImplementedError("n_candidate_gen_per_text > 1 needs the CLAP re-ranker: set "
+                                      "latent_diffusion.clap to a module with cos_similarity(waveform, text) "
+                                      "(audioldm2_amd.clap.CLAPAudioEmbeddingClassifierFreev2), or pass "
+                                      "n_candidate_gen_per_text=1")
+
     @torch.no_grad()
     def generate_batch(self, batch, ddim_steps=200, ddim_eta=1.0, x_T=None, n_gen=1,
                        unconditional_guidance_scale=1.0, unconditional_conditioning=None, use_plms=False,
@@ -510,6 +525,7 @@ class LatentDiffusion(nn.Module):
         draws the posterior sample (one CPU randn of the latent shape, distributions.py:37-41) only to
         read its batch size; we replay the draw and skip the 345 GFLOP encode."""
         assert x_T is None
+        self._check_candidates(n_gen)
         use_ddim = ddim_steps is not None
         # DDPM.get_input maps first_stage_key "fbank" to batch["log_mel_spec"] (ddpm.py:482-522)
         fb = batch["log_mel_spec"] if self.first_stage_key == "fbank" else batch[self.first_stage_key]
@@ -582,6 +598,7 @@ class LatentDiffusion(nn.Module):
         """ddpm.py:1573-1676 (inpainting / super-resolution): VAE-encode the given mel -> x0, keep the
         unmasked latent region (DDIM blends q_sample(x0, t) back in every step), regenerate the rest."""
         assert x_T is None
+        self._check_candidates(n_gen)
         use_ddim = ddim_steps is not None
         fb = batch["log_mel_spec"] if self.first_stage_key == "fbank" else batch[self.first_stage_key]
         x = fb.unsqueeze(1).float().contiguous().to(self.device)  # DDPM.get_input: [B, 1, T, F]

@@ -67,6 +67,19 @@ class ResBlock(nn.Module):
         computed once per forward for all ResBlocks by UNetModel."""
         pk = self._prepare()
         sc, sh = ops.gn_stats(x, *pk["gn1"], groups=32, eps=1e-5, x2=x2)
+        if ops.use_dma() and self.channels % 32 == 0:
+            # GroupNorm apply + SiLU + operand split once per element (aldm_split_rows) instead of once per conv tap in
+            # the GEMM's K loop; the convs then run on the DMA-fed kernel over pre-split operands (csrc/igemm_dma.h)
+            if pk["skip"] is None:
+                assert x2 is None
+                a1, skip = ops.split_rows(x, pre=(sc, sh), act=ACT_SILU), x
+            else:
+                a1, araw = ops.split_rows(x, x2, pre=(sc, sh), act=ACT_SILU, want_raw=True)
+                skip = ops.conv(araw, pk["skip"])
+            h = ops.conv(a1, pk["conv1"], pad=(1, 1), rowbias=e)
+            sc2, sh2 = ops.gn_stats(h, *pk["gn2"], groups=32, eps=1e-5)
+            a2 = ops.split_rows(h, pre=(sc2, sh2), act=ACT_SILU)
+            return ops.conv(a2, pk["conv2"], pad=(1, 1), res=skip)
         h = ops.conv(x, pk["conv1"], x2=x2, pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU, rowbias=e)
         sc2, sh2 = ops.gn_stats(h, *pk["gn2"], groups=32, eps=1e-5)
         if pk["skip"] is None:
@@ -91,6 +104,8 @@ class Downsample(nn.Module):
     def run(self, x):
         if self._pk is None:
             self._pk = ops.pack_conv(self.op.weight, self.op.bias)
+        if ops.use_dma() and self.channels % 32 == 0:
+            x = ops.split_rows(x)
         return ops.conv(x, self._pk, stride=(2, 2), pad=(1, 1))
 
 
@@ -108,6 +123,8 @@ class Upsample(nn.Module):
     def run(self, x):
         if self._pk is None:
             self._pk = ops.pack_conv(self.conv.weight, self.conv.bias)
+        if ops.use_dma() and self.channels % 32 == 0:
+            x = ops.split_rows(x)
         return ops.conv(x, self._pk, pad=(1, 1), up=(2, 2))
 
 
@@ -191,27 +208,32 @@ class BasicTransformerBlock(nn.Module):
             )
         return self._pk
 
-    def run(self, h, context=None, mask=None):
-        """h: [B, L, C] tokens.  attention.py:406-410 (mask is ignored when context is None: :400-404)."""
+    def run(self, h, context=None, mask=None, want_split=False):
+        """h: [B, L, C] tokens.  attention.py:406-410 (mask is ignored when context is None: :400-404).
+        want_split: also return the result as a split image (the operand of SpatialTransformer.proj_out)."""
         pk = self._prepare()
         C = self.dim
-        n = ops.layernorm(h, *pk["ln"][0])
+        # DMA mode: every GEMM operand is written pre-split by its producer (LayerNorm, attention, GEGLU epilogue)
+        so = "only" if (ops.use_dma() and C % 32 == 0) else None
+        n = ops.layernorm(h, *pk["ln"][0], split_out=so)
         qkv = ops.linear(n, pk["qkv1"])
-        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
+        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads, split_out=so)
         h = ops.linear(a, pk["out1"], res=h)
-        n = ops.layernorm(h, *pk["ln"][1])
+        n = ops.layernorm(h, *pk["ln"][1], split_out=so)
         if context is None:
             if pk["qkv2"] is None:
                 raise RuntimeError("attn2 was built with a context_dim but no context was provided")
             qkv = ops.linear(n, pk["qkv2"])
-            a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads)
+            a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads, split_out=so)
         else:
             q = ops.linear(n, pk["q2"])
             kv = self._context_kv(context, pk)
-            a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads, mask=mask)
+            a = ops.attention(q, kv[:, :, :C], kv[:, :, C:], self.heads, mask=mask, split_out=so)
         h = ops.linear(a, pk["out2"], res=h)
-        n = ops.layernorm(h, *pk["ln"][2])
-        g = ops.linear_geglu(n, pk["ff1"])  # Linear(C, 8C) + x*gelu(gate) in one GEMM (attention.py:37-45)
+        n = ops.layernorm(h, *pk["ln"][2], split_out=so)
+        g = ops.linear_geglu(n, pk["ff1"], split_out=so)  # Linear(C, 8C) + x*gelu(gate) in one GEMM (attention.py:37-45)
+        if want_split and so:
+            return ops.linear(g, pk["ff2"], res=h, split_out="also")
         return ops.linear(g, pk["ff2"], res=h)
 
 
@@ -239,6 +261,13 @@ class SpatialTransformer(nn.Module):
         pk = self._pk
         B, H, W, C = x.shape
         sc, sh = ops.gn_stats(x, *pk["gn"], groups=32, eps=1e-6)
+        if ops.use_dma() and C % 32 == 0 and self.proj_in.out_channels % 32 == 0:
+            h = ops.conv(ops.split_rows(x, pre=(sc, sh)), pk["pin"]).view(B, H * W, -1)
+            hs = None
+            for i, blk in enumerate(self.transformer_blocks):
+                r = blk.run(h, context, mask, want_split=i == len(self.transformer_blocks) - 1)
+                h, hs = r if isinstance(r, tuple) else (r, None)
+            return ops.conv((hs if hs is not None else h).view(B, H, W, -1), pk["pout"], res=x)
         h = ops.conv(x, pk["pin"], pre=(sc, sh)).view(B, H * W, -1)
         for blk in self.transformer_blocks:
             h = blk.run(h, context, mask)
@@ -395,20 +424,29 @@ class UNetModel(nn.Module):
             if hasattr(m, "_kv"):
                 m._kv = None
 
-    def refresh_context_kv(self, contexts):
-        """Recompute, IN PLACE, the cached cross-attention K/V projections of the given context tensors
-        (their contents were overwritten for a new sampling run; a captured step graph keeps reading
-        the same K/V buffers)."""
+    def collect_context_kv(self, contexts):
+        """[(block, context, kv)] for every cached cross-attention K/V projection of the given context tensors.  A
+        captured step graph reads exactly these kv buffers: the graph-cache entry keeps this list (and with it the
+        buffers) alive, so nothing a later run does to the blocks' 2-entry lookup lists can free or recycle them."""
+        out = []
         for m in self.modules():
             if isinstance(m, BasicTransformerBlock) and m._kv:
-                pk = m._prepare()
-                new = []
-                for ctx, ver, kv in m._kv:
+                for ctx, _ver, kv in m._kv:
                     if any(ctx is c for c in contexts):
-                        ops.linear(ctx, pk["kv2"], out=kv)
-                        ver = ctx._version
-                    new.append((ctx, ver, kv))
-                m._kv = new
+                        out.append((m, ctx, kv))
+        return out
+
+    def refresh_context_kv(self, entries):
+        """Recompute IN PLACE the K/V projections a captured step graph reads (`entries` from collect_context_kv; the
+        contexts' contents were overwritten for a new sampling run) and put them back at the front of each block's
+        lookup list.  Returns the number of projections refreshed."""
+        n = 0
+        for m, ctx, kv in entries:
+            pk = m._prepare()
+            ops.linear(ctx, pk["kv2"], out=kv)
+            m._kv = [(ctx, ctx._version, kv)] + [c for c in (m._kv or ()) if c[2] is not kv][:1]
+            n += 1
+        return n
 
     def _prepare(self):
         if self._pk is None:

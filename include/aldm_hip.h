@@ -129,6 +129,16 @@ typedef struct aldm_igemm_desc {
        grade) instead of the fp32 MFMA.  NULL => fp32 MFMA.                         */
     const void* w_split;
     int32_t hint_mma;      /* tuned table: 1 = fp32 MFMA even when w_split is set, 0 = automatic          */
+    int32_t hint_stages;   /* DMA-fed kernel: LDS ring depth (0 = automatic)                              */
+    /* ABI v5: pre-split operands ("split images", see aldm_split_rows).  When a_split is set the A operand is NOT
+       gathered from x1/x2 but from the split image of the [B, H, W, C1] input (C1 % 32 == 0, C2 = 0, no prologue:
+       normalisation / activation were applied by whoever wrote the image) and both operands go global -> LDS by
+       DMA (global_load_lds) with no staging registers and no operand arithmetic in the K loop; requires w_split.
+       out_split: the epilogue also (out != NULL) or only (out == NULL) writes its result as a split image with
+       out_split_c channels per row — the A operand of the next GEMM (N % 4 == 0, 16-byte aligned out / res).    */
+    const void* a_split;
+    void* out_split;
+    int32_t out_split_c;
     int32_t reserved0;
 } aldm_igemm_desc;
 
@@ -146,6 +156,9 @@ int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, 
 /* Tuning override (tests / tools): force the block tile and split-K factor of subsequent
  * aldm_igemm calls on this thread; bm = 0 => automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
 void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
+/* ... and the LDS ring depth of the DMA-fed kernel (a_split descriptors): 128x128 {2,3}, 64x128 / 128x64 {2,4},
+ * 64x64 {2,3}; 0 = default for the tile.  aldm_igemm_force() resets it to 0.                                  */
+void aldm_igemm_force_stages(int stages);
 /* Tuning override (tests / tools): bit mask of the block tiles that run with 8 instead of 4 wavefronts per
  * tile on this thread (1: 128x128, 2: 64x128, 4: 128x64 — GroupNorm-prologue launches; 8: 128x128 launches
  * without a prologue too).  mask < 0 restores the default (1, or $ALDM_IGEMM_W8).  Returns the mask in force. */
@@ -159,6 +172,20 @@ int aldm_igemm_mma(int mode);
  * aldm_split_bytes = size of that image.                                                                 */
 int64_t aldm_split_bytes(int K, int N);
 int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* stream);
+
+/* ---- split images: pre-split activations for the DMA-fed GEMM (aldm_igemm_desc.a_split, ABI v5) -----------------
+ * A split image of channels-last fp32 rows [rows, C] (C % 32 == 0) holds every value as its exact 3-way truncation
+ * split x = hi + mid + lo (bf16 bit patterns), blocked [row][C/32][part][32]: 6 bytes per element, 192 contiguous
+ * bytes per (row, 32-channel block).  Producers: aldm_split_rows (below), aldm_layernorm_split,
+ * aldm_attention_d32_split and aldm_igemm's out_split.                                                            */
+int64_t aldm_split_image_bytes(int64_t rows, int C);
+/* dst = split(act(x*scale[b, c] + shift[b, c])) with x = x1 ++ x2 along C ([rows, C1] / [rows, C2], P rows per
+ * sample; scale/shift [rows/P, C1+C2] or NULL = no affine; act = ALDM_ACT_NONE | ALDM_ACT_SILU): GroupNorm apply +
+ * SiLU (openaimodel.py:227-231,280-283; attention.py:459) and the skip concat (openaimodel.py:879) done ONCE per
+ * element instead of once per conv tap inside the GEMM.  dst_raw (optional): split(x) of the same rows (the 1x1 skip
+ * conv's operand, openaimodel.py:267).                                                                            */
+int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                    const float* shift, int act, void* dst, void* dst_raw, void* stream);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1
@@ -176,7 +203,9 @@ int aldm_pack_kn(const float* src, float* dst, int K, int N, int lds, int batch,
 /* GroupNorm statistics over channels-last x = x1 ++ x2 -> per-(b, c) scale/shift such that
  * GroupNorm(x)[b, p, c] = x*scale[b, c] + shift[b, c]  (scale = rstd*gamma,
  * shift = beta - mean*rstd*gamma).  util.py:224-241 (eps 1e-5), attention.py:75-78 and
- * model.py:38-41 (eps 1e-6).  ws: >= B*chunks*G*2 floats scratch (see aldm_gn_ws_floats). */
+ * model.py:38-41 (eps 1e-6).  ws: scratch of aldm_gn_ws_floats() floats.
+ * Statistics are accumulated about a per-thread pivot and merged with the parallel-variance formula in fp64 (fixed
+ * order), so |mean| >> std inputs keep their variance (ATen: Welford). */
 int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1, int C2,
                          int G, float eps, const float* gamma, const float* beta,
                          float* scale, float* shift, float* ws, void* stream);
@@ -184,6 +213,9 @@ int64_t aldm_gn_ws_floats(int B, int P, int C, int G);
 /* LayerNorm over the last dim of [M, C] (attention.py:393-395), eps 1e-5                   */
 int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                    const float* beta, float eps, void* stream);
+/* same, writing the result as a split image (y_split, C % 32 == 0) and optionally also as fp32 (y may be NULL)    */
+int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
+                         const float* beta, float eps, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------ */
 /* Multi-head attention, head dim 32, flash-style online softmax on fp32 MFMA:
@@ -194,6 +226,11 @@ int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
 int aldm_attention_d32(const float* q, const float* k, const float* v, float* out,
                        int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                        const float* mask, float scale, void* stream);
+/* same, writing the result (also / only: out may be NULL) as a split image with heads*32 channels per row — the
+ * pre-split A operand of the to_out projection (attention.py:366)                                               */
+int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
+                             int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                             const float* mask, float scale, void* stream);
 /* Matrix-core path of aldm_attention_d32 on this thread: 1 = fp32 MFMA, 2 = bf16-split (both products as 6 bf16 partial
  * products of exact operand splits, like the igemm engine), -1 = default ($ALDM_ATTN_MMA, "f32" unless it says
  * "bf16x6").  Returns the previous mode.                                                                        */

@@ -1,0 +1,151 @@
+"""DMA-fed bf16-split GEMM over pre-split operands (csrc/igemm_dma.h) and the split-image producers, through the C ABI,
+against plain PyTorch fp32 on the CPU.  Same tolerances as tests/test_ops_gpu.py: contractions max|err|/max|ref| <= 5e-5;
+the split itself is exact (hi + mid + lo == x bitwise)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GEMM_TOL = 5e-5
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def cl(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def uncl(y):
+    return y.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from audioldm2_amd import ops as o
+    prev = o.set_mma("bf16x6")
+    yield o
+    o.set_mma(prev)
+
+
+def test_split_rows_is_exact_and_applies_groupnorm_silu(ops):
+    B, P, C1, C2 = 3, 50, 96, 64
+    x1 = (torch.randn(B, P, C1, generator=g(1)) * 3 + 1).cuda()
+    x2 = torch.randn(B, P, C2, generator=g(2)).cuda() * 1e-3
+    sc = torch.randn(B, C1 + C2, generator=g(3)).cuda()
+    sh = torch.randn(B, C1 + C2, generator=g(4)).cuda()
+    s, raw = ops.split_rows(x1, x2, pre=(sc, sh), act=ops.ACT_SILU, want_raw=True)
+    xc = torch.cat([x1, x2], -1)
+    assert torch.equal(raw.float(), xc), "hi + mid + lo must reproduce x bitwise"
+    ref = F.silu(xc * sc[:, None, :] + sh[:, None, :])
+    assert rel_err(s.float(), ref) < 2e-6
+    s2 = ops.split_rows(x1, pre=(sc[:, :C1].contiguous(), sh[:, :C1].contiguous()))
+    assert torch.equal(s2.float(), x1 * sc[:, None, :C1] + sh[:, None, :C1])
+    # tiny / huge values keep the exact split too
+    z = torch.tensor([1e-36, -3e38, 1.0000001, -0.0, 65504.0, 1e-30, 7.0, 3.14159] * 4).view(1, 1, 32).cuda()
+    assert torch.equal(ops.split_rows(z).float(), z)
+
+
+@pytest.mark.parametrize("B,C,N,H,W,k,s,p,up", [
+    (2, 128, 128, 32, 16, 3, 1, 1, 1),     # UNet level-0 ResBlock conv
+    (1, 128, 128, 300, 16, 3, 1, 1, 1),    # M = 4800: ragged M tile
+    (2, 256, 256, 16, 8, 3, 2, 1, 1),      # Downsample stride 2
+    (2, 256, 256, 8, 4, 3, 1, 1, 2),       # Upsample: nearest x2 in the address generation
+    (2, 640, 640, 4, 2, 3, 1, 1, 1),       # deepest level, tiny M
+    (2, 256, 384, 9, 5, 1, 1, 0, 1),       # 1x1 conv, odd extents
+    (1, 64, 96, 50, 30, 3, 1, 1, 1),       # N = 96: partial column tile
+    (3, 32, 40, 7, 5, 3, 1, 2, 1),         # one k-tile per tap, padding 2, N % 32 != 0
+])
+def test_conv_on_split_operand(ops, B, C, N, H, W, k, s, p, up):
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, k, k, generator=g(2)) / math.sqrt(C * k * k)
+    b = torch.randn(N, generator=g(3))
+    xin = F.interpolate(x, scale_factor=up, mode="nearest") if up > 1 else x
+    ref = F.conv2d(xin, w, b, stride=s, padding=p)
+    pw = ops.pack_conv(w, b)
+    xs = ops.split_rows(cl(x))
+    y = ops.conv(xs, pw, stride=(s, s), pad=(p, p), up=(up, up))
+    assert rel_err(uncl(y), ref) < GEMM_TOL
+
+
+@pytest.mark.parametrize("bm,bn,st", [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2),
+                                      (64, 64, 3), (64, 64, 2)])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_dma_every_tile_and_splitk(ops, bm, bn, st, splits):
+    """Every instantiation, with and without split-K, ragged M, K = 38 k-tiles (ragged split), full epilogue, and the
+    split-image second output equal to the fp32 one."""
+    B, C, N, H, W = 3, 128, 96, 13, 7
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    b = torch.randn(N, generator=g(3))
+    emb = torch.randn(B, 2 * N, generator=g(4))
+    res = torch.randn(B, N, H, W, generator=g(5))
+    ref = F.silu(F.conv2d(x, w, b, padding=1) + emb[:, N:, None, None]) + res
+    pw = ops.pack_conv(w, b)
+    xs = ops.split_rows(cl(x))
+    ops.igemm_force(bm, bn, splits, 0, st)
+    try:
+        y1, s1 = ops.conv(xs, pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res), split_out="also")
+        y2 = ops.conv(xs, pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res))
+        s3 = ops.conv(xs, pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res), split_out="only")
+    finally:
+        ops.igemm_force(0, 0, 0)
+    assert rel_err(uncl(y1), ref) < GEMM_TOL
+    assert torch.equal(y1, y2), "must be bitwise reproducible"
+    assert torch.equal(s1.float(), y1) and torch.equal(s3.float(), y1)
+
+
+def test_dma_matches_register_staged_kernel_bitwise_class(ops):
+    """Same arithmetic as the register-staged bf16-split kernel: results agree to fp32 summation-order noise."""
+    B, C, N, H, W = 2, 256, 256, 16, 8
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    pw = ops.pack_conv(w, None)
+    y_old = ops.conv(cl(x), pw, pad=(1, 1))
+    y_new = ops.conv(ops.split_rows(cl(x)), pw, pad=(1, 1))
+    assert rel_err(y_new, y_old) < 2e-6
+
+
+def test_linear_geglu_layernorm_attention_split_chain(ops):
+    """LayerNorm -> (split) -> GEGLU projection -> (split) -> FF out projection, and attention -> (split) -> out
+    projection: the transformer block's GEMM chain with no fp32 operand between producer and consumer."""
+    M, C = 300, 256
+    x = torch.randn(2, M // 2, C, generator=g(1))
+    ga, be = torch.randn(C, generator=g(2)), torch.randn(C, generator=g(3))
+    w1 = torch.randn(8 * C, C, generator=g(4)) / math.sqrt(C)
+    b1 = torch.randn(8 * C, generator=g(5))
+    w2 = torch.randn(C, 4 * C, generator=g(6)) / math.sqrt(4 * C)
+    b2 = torch.randn(C, generator=g(7))
+    n_ref = F.layer_norm(x, (C,), ga, be, 1e-5)
+    h = n_ref @ w1.t() + b1
+    a, gate = h.chunk(2, -1)
+    ff_ref = (a * F.gelu(gate)) @ w2.t() + b2 + x
+    n_f, n_s = ops.layernorm(x.cuda(), ga.cuda(), be.cuda(), split_out="also")
+    assert rel_err(n_f, n_ref) < 2e-6 and torch.equal(n_s.float(), n_f)
+    gs = ops.linear_geglu(n_s, ops.pack_geglu(w1, b1), split_out="only")
+    y = ops.linear(gs, ops.pack_conv(w2, b2), res=x.cuda())
+    assert rel_err(y, ff_ref) < GEMM_TOL
+    # attention with a split-image output
+    heads, Lq, Lk = 8, 70, 45
+    q = torch.randn(2, Lq, heads * 32, generator=g(8))
+    k = torch.randn(2, Lk, heads * 32, generator=g(9))
+    v = torch.randn(2, Lk, heads * 32, generator=g(10))
+    o_f, o_s = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, split_out="also")
+    assert torch.equal(o_s.float(), o_f)
+    o_only = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, split_out="only")
+    assert torch.equal(o_only.float(), o_f)
+    qh = q.view(2, Lq, heads, 32).transpose(1, 2)
+    kh = k.view(2, Lk, heads, 32).transpose(1, 2)
+    vh = v.view(2, Lk, heads, 32).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(2, Lq, heads * 32)
+    assert rel_err(o_f, ref) < GEMM_TOL

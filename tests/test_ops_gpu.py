@@ -410,6 +410,43 @@ def test_groupnorm_stats(ops, B, P, C, eps):
     assert rel_err(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("ratio", [1e2, 1e3])
+@pytest.mark.parametrize("B,P,C", [(2, 4096, 128), (2, 64, 640), (1, 1000, 256)])
+def test_groupnorm_stats_large_mean(ops, ratio, B, P, C):
+    """|mean| >> std (a trained checkpoint's post-conv activations): single-pass E[x^2] - E[x]^2 in fp32 loses the
+    variance here; the pivot-shifted / Chan-merged statistics must hold 5e-5 against F.group_norm in fp64 (ATen's fp32
+    GroupNorm is Welford).  Both the two-launch and the one-block-per-sample (small P*C) forms are covered."""
+    x = (torch.randn(B, P, C, generator=g(1)) + ratio * (1 + torch.arange(C) % 7).float() / 4)
+    gamma = torch.randn(C, generator=g(2))
+    beta = torch.randn(C, generator=g(3))
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), eps=1e-5).permute(0, 2, 1)
+    sc, sh = ops.gn_stats(x.cuda(), gamma.cuda(), beta.cuda(), groups=32, eps=1e-5)
+    got = torch.addcmul(sh.cpu().double()[:, None, :], x.double(), sc.cpu().double()[:, None, :])
+    assert rel_err(got, ref) < 5e-5
+    # the statistics themselves: rstd to 1e-5 relative
+    xg = x.double().view(B, P, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+    rstd = (xg.var(-1, unbiased=False) + 1e-5).rsqrt().repeat_interleave(C // 32, 1) * gamma.double()
+    assert rel_err(sc, rstd) < 1e-5
+
+
+def test_groupnorm_stats_constant_channels(ops):
+    """A constant input (variance exactly 0): mean exact, rstd = 1/sqrt(eps), no NaN from a negative variance.  The
+    engine applies GroupNorm as x*scale + shift (scale = rstd*gamma, shift = beta - mean*scale), so the output error is
+    bounded by the fp32 rounding of the two O(|x|*scale) terms: <= 4 * |x| * |scale| * 2^-24."""
+    B, P, C = 2, 300, 128
+    x = torch.full((B, P, C), 37.25)
+    x[1] = -3.0
+    gamma = torch.randn(C, generator=g(2))
+    beta = torch.randn(C, generator=g(3))
+    sc, sh = ops.gn_stats(x.cuda(), gamma.cuda(), beta.cuda(), groups=32, eps=1e-5)
+    assert torch.isfinite(sc).all() and torch.isfinite(sh).all()
+    assert rel_err(sc, (gamma * 1e-5 ** -0.5).expand(B, C)) < 1e-6
+    got = x * sc.cpu()[:, None, :] + sh.cpu()[:, None, :]
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), eps=1e-5).permute(0, 2, 1)
+    bound = 4 * x.abs() * sc.cpu().abs()[:, None, :] * 2.0 ** -24 + 1e-6
+    assert ((got.double() - ref).abs() <= bound).all()
+
+
 @pytest.mark.parametrize("M,C", [(1024, 256), (300, 384), (64, 640), (10, 1280)])
 def test_layernorm(ops, M, C):
     x = torch.randn(M, C, generator=g(1)) * 2 + 0.3
