@@ -212,7 +212,9 @@ TUNE_LOG = None  # when a list: every launch's geometry key is appended (tools/i
 
 
 def tune_key(d: IgemmDesc) -> str:
-    return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}"
+    """Geometry key of a launch (tuned tables, TUNE_LOG); DMA-fed launches (pre-split A operand) carry a ",dma" suffix:
+    they have their own kernel family and table."""
+    return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}" + (",dma" if d.a_split else "")
 
 
 def _tuned_table(bx=False):

@@ -2,10 +2,7 @@
 (audioldm2_amd/seqgen.py) against the fixtures produced by the REAL reference class (`Sequence2AudioMAE.generate`,
 tests/golden/seqgen_*; the oracle and the module's host logic are pinned to the same fixtures on the CPU).
 
-Everything here was written after round 1's GPU budget was spent — the masked softmax kernel, the tanh-GELU epilogue
-and the module have never run on hardware.  A kernel fault would take the whole pytest process down, so the module only
-runs when ALDM_EXPERIMENTAL=1 is set (first thing next round: `ALDM_EXPERIMENTAL=1 pytest tests/test_seqgen_gpu.py -m gpu`);
-drop the guard once it has passed on an MI355X.  Sorted last on purpose."""
+First hardware run: round 2 (7 passed on an MI355X, gpurun_out/r2/seqgen_test.log); the round-1 opt-in guard is gone."""
 import json
 import math
 import os
@@ -17,9 +14,7 @@ import torch.nn.functional as F
 
 from oracle import cases, weights
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("ALDM_EXPERIMENTAL", "0") != "1",
-                                 reason="next scope row: first hardware run pending, opt in with ALDM_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 

@@ -1,0 +1,89 @@
+"""Measure the best (block tile, LDS ring depth, split-K) of the DMA-fed igemm (csrc/igemm_dma.h) for every geometry a
+model's sampling job launches on it and write audioldm2_amd/tuning/mi355x_igemm_dma.json ({key: [BM, BN, splits, stages,
+best_us, auto_us]}).  Keys are collected from one short eager job (ops.TUNE_LOG, ",dma" keys).
+Usage (GPU box): python tools/dma_autotune.py out.json [model ...]"""
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.argv_saved = list(sys.argv)
+sys.argv = [sys.argv[0], "--mma", "bf16x6"]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import igemm_autotune as at  # noqa: E402  (sets ALDM_NO_GRAPH / ALDM_NO_TUNING, BX = True)
+sys.argv = sys.argv_saved
+from audioldm2_amd import lib as L  # noqa: E402
+from audioldm2_amd import ops  # noqa: E402
+
+CFGS = [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2), (64, 64, 3),
+        (64, 64, 2)]
+SPLITS = [1, 2, 3, 4, 6, 8]
+
+
+def tune(key, lib):
+    d, keep, M, N, K = at.make_desc(key[:-len(",dma")])
+    npix = d.B * d.H * d.W
+    img = torch.randint(-2 ** 15, 2 ** 15, (npix * (d.C1 // 32) * 96,), device="cuda", dtype=torch.int16)
+    d.a_split = img.data_ptr()
+    d.x1 = None
+    d.pre_scale = d.pre_shift = None
+    d.pre_act = 0
+    nk = K // 32
+    flops = 2.0 * M * N * K
+    reps = 3 if flops > 2e10 else 8
+    d.hint_bm = d.hint_bn = d.hint_splits = d.hint_stages = 0
+    t_auto = at.time_launch(lib, d, reps)
+    best = (t_auto, 0, 0, 0, 0)
+    geglu = d.epi_mode == L.EPI_GEGLU
+    for bm, bn, st in CFGS:
+        if geglu and bn != 128:
+            continue
+        if bn > 64 and N <= 64 and not geglu:
+            continue
+        if bm > 64 and M <= 64:
+            continue
+        for sp in SPLITS:
+            if sp > 1 and (geglu or N % 4 or nk < 8 or nk // sp < 2):
+                continue
+            blocks = math.ceil(M / bm) * math.ceil(N / bn) * sp
+            if sp > 1 and blocks > 2048:
+                continue
+            d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = bm, bn, sp, st
+            t = at.time_launch(lib, d, reps)
+            if t is not None and t < best[0]:
+                best = (t, bm, bn, sp, st)
+    return t_auto, best, flops, (M, N, K)
+
+
+def main():
+    out = sys.argv[1]
+    models = sys.argv[2:] or ["audioldm2-full"]
+    ops.set_mma("bf16x6")
+    ops.set_dma(True)
+    lib = L.load()
+    counts = {}
+    for m in models:
+        c = at.collect(m, 8)
+        for k, n in c.items():
+            if k.endswith(",dma"):
+                counts[k] = max(counts.get(k, 0), n)
+        print(f"# {m}: {sum(1 for k in c if k.endswith(',dma'))} unique DMA-fed igemm geometries", flush=True)
+    entries, total, saved = {}, 0.0, 0.0
+    for key, n in sorted(counts.items()):
+        t_auto, best, flops, mnk = tune(key, lib)
+        total += t_auto * n
+        if best[1] and best[0] < 0.97 * t_auto:
+            entries[key] = [best[1], best[2], best[3], best[4], round(best[0], 1), round(t_auto, 1)]
+            saved += (t_auto - best[0]) * n
+        print(f"M{mnk[0]} N{mnk[1]} K{mnk[2]} n={n} auto {t_auto:.1f}us -> best {best[1]}x{best[2]} k{best[3]} st{best[4]} "
+              f"{best[0]:.1f}us {flops / best[0] / 1e6:.1f} TF", flush=True)
+    with open(out, "w") as f:
+        json.dump({"device": "MI355X", "kernel": "igemm_dma_kernel", "entries": entries}, f, indent=0, sort_keys=True)
+    print(f"# {len(entries)} tuned entries, {saved / 1e3:.2f} ms of {total / 1e3:.2f} ms (2-step job) saved", flush=True)
+
+
+if __name__ == "__main__":
+    main()
