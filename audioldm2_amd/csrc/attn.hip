@@ -50,7 +50,7 @@ template <bool HAS_MASK, int QT, bool BX = false>
 __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
-    const float* __restrict__ mask, float scale, void* __restrict__ out_split, int split_c) {
+    const float* __restrict__ mask, float scale, void* __restrict__ out_split, int split_c, int parts) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l31 = lane & 31;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
                 for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
                 if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
                 // a head = one 32-channel block of the split image (the out-projection GEMM's pre-split A operand)
-                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x);
+                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
             }
         }
     }
@@ -234,13 +234,14 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 
 using namespace aldm;
 
-// matrix-core path of the attention kernel: -1 = default ($ALDM_ATTN_MMA: "bf16x6" or "f32"; f32 until the split
-// kernel has been validated on hardware), 1 = fp32 MFMA, 2 = bf16-split
+// matrix-core path of the attention kernel: -1 = default (bf16-split since round 2: 1024x1024 self-attention 202 -> 139 us
+// on MI355X, agreement with the fp32-MFMA kernel 1.6e-6, profiles/r02_attn_ab.txt; $ALDM_ATTN_MMA=f32 switches back),
+// 1 = fp32 MFMA, 2 = bf16-split
 static thread_local int g_attn_mma = -1;
 static bool default_attn_bx() {
     static const bool v = [] {
         const char* e = getenv("ALDM_ATTN_MMA");
-        return e != nullptr && e[0] == 'b';
+        return !(e != nullptr && e[0] == 'f');
     }();
     return v;
 }
@@ -250,10 +251,11 @@ extern "C" int aldm_attention_mma(int mode) {
     return prev;
 }
 
-static int attention_launch(const float* q, const float* k, const float* v, float* out, void* out_split, int B,
+static int attention_launch(const float* q, const float* k, const float* v, float* out, void* out_split, int parts, int B,
                             int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                             const float* mask, float scale, void* stream) {
     ALDM_CHECK(q && k && v && (out || out_split), "aldm_attention_d32: null pointer");
+    ALDM_CHECK(parts == 2 || parts == 3, "aldm_attention_d32: parts must be 2 or 3");
     ALDM_CHECK((reinterpret_cast<uintptr_t>(out_split) & 15) == 0, "aldm_attention_d32: out_split must be 16-byte aligned");
     const int split_c = heads * 32;
     if (!out) ldo = heads * 32;
@@ -277,7 +279,7 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
 #define ALDM_ATTN(M_, Q_, X_)                                                                                 \
     hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
-                       ldk, ldv, ldo, mask, scale, out_split, split_c)
+                       ldk, ldv, ldo, mask, scale, out_split, split_c, parts)
 #define ALDM_ATTN_X(M_, Q_)          \
     do {                             \
         if (bx) ALDM_ATTN(M_, Q_, true); \
@@ -300,11 +302,11 @@ extern "C" int aldm_attention_d32(const float* q, const float* k, const float* v
                                   int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                                   const float* mask, float scale, void* stream) {
     ALDM_CHECK(out != nullptr, "aldm_attention_d32: null pointer");
-    return attention_launch(q, k, v, out, nullptr, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, mask, scale, stream);
+    return attention_launch(q, k, v, out, nullptr, 3, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, mask, scale, stream);
 }
 
 extern "C" int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
-                                        int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                                        int parts, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                                         const float* mask, float scale, void* stream) {
-    return attention_launch(q, k, v, out, out_split, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, mask, scale, stream);
+    return attention_launch(q, k, v, out, out_split, parts, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, mask, scale, stream);
 }

@@ -20,8 +20,8 @@ int igemm_launch_bx_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 gr
 int igemm_launch_bx_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // DMA-fed kernel over pre-split operands (igemm_dma.hip)
-int igemm_launch_dma(int BM, int BN, int nst, dim3 grid, hipStream_t st, const IgemmK& p);
-bool igemm_dma_config_ok(int BM, int BN, int nst);
+int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
+bool igemm_dma_config_ok(int BM, int BN, int nst, int parts);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) outp[o + j] = r[j];
     }
-    if (d.out_split) split_store4(d.out_split, orow, d.out_split_c, n, r);
+    if (d.out_split) split_store4(d.out_split, orow, d.out_split_c, n, r, d.split_parts);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,6 +135,7 @@ __global__ void pack_kn_kernel(const float* __restrict__ src, float* __restrict_
 // packed fp32 [Kg][Npad][4] -> bf16-split image [Ko][3][Npad][8 bf16], Ko = 4*ceil(Kg/8) k-octets (zero
 // padded to whole k-tiles): part 0/1/2 = hi/mid/lo of the exact truncation split w = hi + mid + lo (each
 // part = the top 16 bits of an fp32), element j of a slot = k 8*ko + j.  Same split as the kernel's A side.
+template <int NP>
 __global__ void pack_split_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int Kg, int Npad,
                                   int Ko) {
     const int64_t total = (int64_t)Ko * Npad;
@@ -142,34 +143,22 @@ __global__ void pack_split_kernel(const float* __restrict__ src, uint4* __restri
          i += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(i % Npad);
         const int ko = (int)(i / Npad);
-        float v[8];
+        u32x2 part[2][3];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kg = 2 * ko + h;
             f32x4 f = {0.f, 0.f, 0.f, 0.f};
             if (kg < Kg) f = *reinterpret_cast<const f32x4*>(src + ((int64_t)kg * Npad + n) * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[4 * h + c] = f[c];
-        }
-        unsigned part[3][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned u0 = __builtin_bit_cast(unsigned, v[j]);
-            const float r1 = v[j] - __builtin_bit_cast(float, u0 & 0xFFFF0000u);
-            const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-            const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
-            part[0][j] = u0 >> 16;
-            part[1][j] = u1 >> 16;
-            part[2][j] = __builtin_bit_cast(unsigned, r2) >> 16;
+            split4_parts(f, part[h], NP);   // same split as the activations' (igemm_epilogue.h)
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             uint4 o;
-            o.x = part[q][0] | (part[q][1] << 16);
-            o.y = part[q][2] | (part[q][3] << 16);
-            o.z = part[q][4] | (part[q][5] << 16);
-            o.w = part[q][6] | (part[q][7] << 16);
-            dst[((int64_t)ko * 3 + q) * Npad + n] = o;
+            o.x = part[0][q][0];
+            o.y = part[0][q][1];
+            o.z = part[1][q][0];
+            o.w = part[1][q][1];
+            dst[((int64_t)ko * NP + q) * Npad + n] = o;
         }
     }
 }
@@ -237,6 +226,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     aldm_igemm_desc& d = p.d;
     ALDM_CHECK((d.x1 || d.a_split) && d.w && (d.out || d.out_split), "aldm_igemm: null x1/w/out");
     if (!d.x1) d.x1 = reinterpret_cast<const float*>(d.a_split);  // never dereferenced on the DMA path
+    if (d.split_parts == 0) d.split_parts = 3;
+    ALDM_CHECK(d.split_parts == 2 || d.split_parts == 3, "aldm_igemm: split_parts must be 0 / 3 or 2");
     if (!d.x2) d.C2 = 0;
     if (d.pix1 == 0) d.pix1 = d.C1;
     if (d.pix2 == 0) d.pix2 = d.C2;
@@ -324,7 +315,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
                    "aldm_igemm: a_split needs one source with C1 %% 32 == 0 and no prologue (C1=%d C2=%d)", d.C1, d.C2);
         ALDM_CHECK(((reinterpret_cast<uintptr_t>(d.a_split) | reinterpret_cast<uintptr_t>(d.w_split)) & 15) == 0,
                    "aldm_igemm: split images must be 16-byte aligned");
-        ALDM_CHECK((int64_t)d.B * d.H * d.W * p.Cin * 6 < (1ll << 40), "aldm_igemm: split image too large");
+        ALDM_CHECK((int64_t)d.B * d.H * d.W * p.Cin * 2 * d.split_parts < (1ll << 40), "aldm_igemm: split image too large");
         const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu;
         const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
         auto dma_cost = [&](int bm, int bn, int nst, int sp, int* sp_eff) -> double {
@@ -332,10 +323,10 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             sp = cdiv(nk, kt);
             *sp_eff = sp;
             const double blocks = (double)cdiv64(Mz, bm) * cdiv(d.N, bn) * sp;
-            const int lds = nst * (bm + bn) * 192;
+            const int lds = nst * (bm + bn) * 64 * d.split_parts;
             const int o = std::min(2, (160 * 1024) / lds);
-            const double tile_c = (bm / 64) * (bn / 64) * 384.0;   // MFMA cycles of one wave per k-tile
-            const double dma_c = (bm + bn) * 192.0 / 56.0;         // L2 -> LDS at ~56 B/clk/CU
+            const double tile_c = (bm / 64) * (bn / 64) * 64.0 * (d.split_parts == 3 ? 6 : 3);   // MFMA cycles per k-tile
+            const double dma_c = (bm + bn) * 64.0 * d.split_parts / 56.0;   // L2 -> LDS at ~56 B/clk/CU
             const double L = kt * std::max(tile_c, dma_c);
             const double one = kt * std::max(tile_c + 200.0, dma_c) + 6000.0;
             const int64_t nb = (int64_t)((blocks + 255.0) / 256.0);
@@ -352,18 +343,23 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         if (f_bm) {
             BM = f_bm;
             BN = f_bn;
-            nst = f_st > 0 ? f_st : (BM == 256 ? 2 : (BM == 128 && BN == 128 ? 3 : (BM == 64 && BN == 64 ? 3 : 4)));
-            ALDM_CHECK(igemm_dma_config_ok(BM, BN, nst), "aldm_igemm: no DMA kernel for tile %dx%d, %d stages", BM, BN, nst);
+            nst = f_st > 0 ? f_st
+                           : (BM == 256 ? (d.split_parts == 3 ? 2 : 3)
+                                        : (BM == 128 && BN == 128 ? (d.split_parts == 3 ? 3 : 4)
+                                                                  : (BM == 64 && BN == 64 ? 3 : 4)));
+            ALDM_CHECK(igemm_dma_config_ok(BM, BN, nst, d.split_parts), "aldm_igemm: no DMA kernel for tile %dx%d, %d stages", BM, BN, nst);
             if (f_sp > 0 && can_split && nk / f_sp >= 1) splits = f_sp;
         } else {
-            static const int cand[4][3] = {{128, 128, 3}, {64, 128, 4}, {128, 64, 4}, {64, 64, 3}};
+            const int cand[5][3] = {{256, 128, d.split_parts == 3 ? 2 : 3}, {128, 128, d.split_parts == 3 ? 3 : 4},
+                                    {64, 128, 2}, {128, 64, 2}, {64, 64, 2}};
             static const int sps[8] = {1, 2, 3, 4, 6, 8, 12, 16};
             double best = 1e300;
             BM = BN = 64;
             nst = 3;
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 5; ++c) {
                 const int bm = cand[c][0], bn = cand[c][1];
                 if (geglu ? bn != 128 : (bn > 64 && d.N <= 64)) continue;
+                if (bm == 256 && Mz < 4096) continue;
                 for (int si = 0; si < 8; ++si) {
                     const int sp = sps[si];
                     if (sp > 1 && (!can_split || !have_ws || nk / sp < 3)) break;
@@ -397,7 +393,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         p.nst = nst;
         return 0;
     }
-    const bool bx_ok = d.w_split != nullptr && d.b_mode == ALDM_B_PACKED && d.stride_w == 0 && d.batch == 1 &&
+    const bool bx_ok = d.w_split != nullptr && d.split_parts == 3 && d.b_mode == ALDM_B_PACKED && d.stride_w == 0 && d.batch == 1 &&
                        pre != PRE_GENERIC && (reinterpret_cast<uintptr_t>(d.w_split) & 15) == 0 &&
                        (g_force_mma == 2 || (g_force_mma == 0 && d.hint_mma != 1));
     auto occ_of = [&](int bm, int bn) {
@@ -511,6 +507,13 @@ extern "C" int aldm_igemm_plan(const aldm_igemm_desc* dd, int* bm, int* bn, int6
     return 0;
 }
 
+extern "C" int aldm_igemm_plan_stages(const aldm_igemm_desc* dd) {
+    IgemmK p;
+    int BM, BN;
+    if (igemm_prepare(dd, p, BM, BN)) return -1;
+    return p.dma ? p.nst : 0;
+}
+
 extern "C" int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* dd) {
     if (!dd) return 0;
     // ask with an "infinite" dummy workspace to learn the split the heuristic wants
@@ -545,7 +548,7 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
                     (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
     if (p.dma) {
-        rc = igemm_launch_dma(BM, BN, p.nst, grid, st, p);
+        rc = igemm_launch_dma(BM, BN, p.nst, d.split_parts, grid, st, p);
     } else if (p.bx) {
         switch (pre) {
             case PRE_NONE: rc = igemm_launch_bx_pre0(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
@@ -574,15 +577,16 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     return 0;
 }
 
-extern "C" int64_t aldm_split_bytes(int K, int N) {
-    if (K <= 0 || N <= 0) return 0;
+extern "C" int64_t aldm_split_bytes_parts(int K, int N, int parts) {
+    if (K <= 0 || N <= 0 || (parts != 2 && parts != 3)) return 0;
     const int Npad = (N + 31) / 32 * 32;
     const int64_t Ko = 4ll * ((K + 31) / 32);  // k-octets, padded to whole 32-wide k-tiles
-    return Ko * 3 * Npad * 16;
+    return Ko * parts * Npad * 16;
 }
+extern "C" int64_t aldm_split_bytes(int K, int N) { return aldm_split_bytes_parts(K, N, 3); }
 
-extern "C" int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* stream) {
-    ALDM_CHECK(packed && dst && K > 0 && N > 0, "aldm_pack_split_bf16: bad args");
+extern "C" int aldm_pack_split_bf16_parts(const float* packed, void* dst, int K, int N, int parts, void* stream) {
+    ALDM_CHECK(packed && dst && K > 0 && N > 0 && (parts == 2 || parts == 3), "aldm_pack_split_bf16: bad args");
     ALDM_CHECK(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
                "aldm_pack_split_bf16: operands must be 16-byte aligned");
     const int Npad = (N + 31) / 32 * 32;
@@ -590,10 +594,17 @@ extern "C" int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N
     const int Ko = 4 * ((K + 31) / 32);
     const int64_t total = (int64_t)Ko * Npad;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 65535);
-    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed,
-                       reinterpret_cast<uint4*>(dst), Kg, Npad, Ko);
+    if (parts == 3)
+        hipLaunchKernelGGL(pack_split_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed,
+                           reinterpret_cast<uint4*>(dst), Kg, Npad, Ko);
+    else
+        hipLaunchKernelGGL(pack_split_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed,
+                           reinterpret_cast<uint4*>(dst), Kg, Npad, Ko);
     ALDM_LAUNCH_CHECK("aldm_pack_split_bf16");
     return 0;
+}
+extern "C" int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* stream) {
+    return aldm_pack_split_bf16_parts(packed, dst, K, N, 3, stream);
 }
 
 extern "C" int aldm_pack_weight(const float* src, float* dst, int N, int Cin, int KH, int KW,

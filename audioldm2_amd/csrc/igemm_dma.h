@@ -36,10 +36,10 @@ namespace aldm {
 // zero padding / out-of-range columns are fetched from here (one copy per translation unit)
 static __device__ __attribute__((aligned(256))) unsigned g_dma_zero_page[256 + 64];
 
-constexpr int dma_stage_slots(int BM, int BN) { return (BM + BN) * 12; }   // 16-byte slots of one k-tile image
-constexpr int dma_lds_bytes(int BM, int BN, int NST) { return NST * dma_stage_slots(BM, BN) * 16; }
-constexpr int dma_blocks_per_cu(int BM, int BN, int NST) {
-    return (160 * 1024) / dma_lds_bytes(BM, BN, NST) >= 2 ? 2 : 1;
+constexpr int dma_stage_slots(int BM, int BN, int NP) { return (BM + BN) * 4 * NP; }   // 16-byte slots of one k-tile image
+constexpr int dma_lds_bytes(int BM, int BN, int NST, int NP) { return NST * dma_stage_slots(BM, BN, NP) * 16; }
+constexpr int dma_blocks_per_cu(int BM, int BN, int NST, int NP) {
+    return (160 * 1024) / dma_lds_bytes(BM, BN, NST, NP) >= 2 ? 2 : 1;
 }
 
 // s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14):
@@ -51,21 +51,33 @@ __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
 }
 
+// K order of a conv's k-tiles: 0 = tap outer, channel block inner (row pointers recomputed once per tap: the shipped
+// order); 1 = channel block outer, tap inner (the 9 taps of a block re-read one L2-resident patch, but every k-tile pays
+// the row-pointer arithmetic).  Measured on MI355X (profiles/r02_dma_taporder_ab.txt): no gain from 1 — the tap
+// re-reads are served by the 256 MiB Infinity Cache at the same rate — and the 64x64 tiles lose.
+#ifndef ALDM_DMA_TAP_INNER
+#define ALDM_DMA_TAP_INNER 0
+#endif
 #ifndef ALDM_DMA_ABLATE
 #define ALDM_DMA_ABLATE 0  // debug builds only (tools/gpu/build_variant.sh): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads
 #endif
 
-// WM x 2 waves (WM = 2: 256 threads, one wave per SIMD and block; WM = 4: 512 threads, the 256-row tiles)
-template <int BM, int BN, int NST, int WM = 2>
-__global__ __launch_bounds__(128 * WM, dma_blocks_per_cu(BM, BN, NST) * (WM / 2))
+// WM x 2 waves (WM = 2: 256 threads, one wave per SIMD and block; WM = 4: 512 threads, the 256-row tiles).
+// NP = parts per operand: 3 = "bf16x6" (exact 3-way split, 6 partial products, fp32-grade products), 2 = "bf16x3"
+// (hi + mid, both rounded to nearest: 16 significant bits per operand, 3 partial products hi*hi + hi*mid + mid*hi).
+template <int BM, int BN, int NST, int WM = 2, int NP = 3>
+__global__ __launch_bounds__(128 * WM, dma_blocks_per_cu(BM, BN, NST, NP) * (WM / 2))
 void igemm_dma_kernel(const IgemmK p) {
     constexpr int WN = 2, NW = WM * WN;
     constexpr int MT = BM / (32 * WM), NT = BN / 64;
-    constexpr int STG = dma_stage_slots(BM, BN);
-    constexpr int RA = BM / (16 * NW);        // A row groups (16 rows x 3 parts) per wave = A rows per thread
-    constexpr int NB = 12 * (BN / 64) / NW;   // B chunks per wave
-    constexpr int D = 3 * RA + NB;            // LDS-DMA instructions per thread and k-tile
-    static_assert(BM % (16 * NW) == 0 && (12 * (BN / 64)) % NW == 0, "DMA chunks must divide among the waves");
+    constexpr int STG = dma_stage_slots(BM, BN, NP);
+    constexpr int PB = 64 * NP;               // bytes of one (row, 32-channel block) of a split image
+    constexpr int RA = BM / (16 * NW);        // A row groups (16 rows x NP parts) per wave = A rows per thread
+    constexpr int NB = 4 * NP * (BN / 64) / NW;   // B chunks per wave
+    constexpr int D = NP * RA + NB;           // LDS-DMA instructions per thread and k-tile
+    constexpr int NPROD = NP == 3 ? 6 : 3;    // bf16 partial products per fp32 product
+    static_assert(NP == 2 || NP == 3, "2 or 3 parts");
+    static_assert(BM % (16 * NW) == 0 && (4 * NP * (BN / 64)) % NW == 0, "DMA chunks must divide among the waves");
     static_assert(NST >= 2 && NST <= 4 && (NST - 1) * D <= 63, "ring depth / vmcnt range");
     static_assert(NW * 32 * (NT * 32 + 4) * 4 <= NST * STG * 16, "epilogue staging must fit the ring");
     __shared__ u32x4 smem[NST * STG];   // the ONLY LDS object (a second one makes hipcc drain vmcnt before every ds_read)
@@ -97,10 +109,12 @@ void igemm_dma_kernel(const IgemmK p) {
     const char* zero = reinterpret_cast<const char*>(g_dma_zero_page);
     const char* abase = reinterpret_cast<const char*>(d.a_split);
     const char* wbase = reinterpret_cast<const char*>(d.w_split);
-    const int cpb = p.Cin >> 5;                       // k-tiles (32-channel blocks) per tap
-    const int64_t rowbytes = (int64_t)cpb * SPLIT_BLOCK_BYTES;
+    const int cpb = p.Cin >> 5;                       // 32-channel blocks per tap
+    const int taps = d.KH * d.KW;
+    const int64_t rowbytes = (int64_t)cpb * PB;
+    // K order: see ALDM_DMA_TAP_INNER above (k-tile kt = tap * cpb + cb in the shipped order, matching the weights).
 
-    // ---- A bookkeeping: this thread fetches row (wave*RA + i)*16 + lane/4, slot lane%4 of each of the 3 parts ----
+    // ---- A bookkeeping: this thread fetches row (wave*RA + i)*16 + lane/4, slot lane%4 of each of the NP parts ----
     const int lane_off = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;   // swizzled source octet of this lane's LDS slot
     int a_pix[RA], a_h[RA], a_w[RA];
 #pragma unroll
@@ -121,39 +135,47 @@ void igemm_dma_kernel(const IgemmK p) {
         }
     }
     const char* a_ptr[RA];
-    int a_step[RA];
+    int a_step[RA];         // bytes to the next channel block of the same pixel (0 for rows on the zero page)
     int t_kh, t_kw, t_cb;   // (tap, channel block) of the NEXT k-tile to issue
-    auto set_tap = [&]() {
+    auto set_tap = [&]() {  // row pointers of tap (t_kh, t_kw), channel block t_cb; zero padding -> the zero page
         const int dh = t_kh * d.DH, dw = t_kw * d.DW;
+        const int cboff = t_cb * PB + lane_off;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int ihv = a_h[i] + dh, iwv = a_w[i] + dw;
             const bool ok = (unsigned)ihv < (unsigned)p.HV && (unsigned)iwv < (unsigned)p.WV;
             const int pix = (a_pix[i] + (ihv >> p.shh)) * d.W + (iwv >> p.shw);
-            a_ptr[i] = (ok ? abase + (int64_t)pix * rowbytes : zero) + lane_off;
-            a_step[i] = ok ? SPLIT_BLOCK_BYTES : 0;
+            a_ptr[i] = ok ? abase + ((int64_t)pix * rowbytes + cboff) : zero + lane_off;
+            a_step[i] = ok ? PB : 0;
         }
     };
     {
-        const int tap = kt0 / cpb;
-        t_cb = kt0 - tap * cpb;
-        t_kh = tap / d.KW;
-        t_kw = tap - t_kh * d.KW;
+        if (ALDM_DMA_TAP_INNER) {
+            t_cb = kt0 / taps;
+            const int tap = kt0 - t_cb * taps;
+            t_kh = tap / d.KW;
+            t_kw = tap - t_kh * d.KW;
+        } else {
+            const int tap = kt0 / cpb;
+            t_cb = kt0 - tap * cpb;
+            t_kh = tap / d.KW;
+            t_kw = tap - t_kh * d.KW;
+        }
         set_tap();
-#pragma unroll
-        for (int i = 0; i < RA; ++i) a_ptr[i] += (int64_t)t_cb * a_step[i];
     }
-    // ---- B bookkeeping: chunk c = wave*NB + j -> (slot row = octet*3 + part, 64-column half) ----
+    // ---- B bookkeeping: chunk c = wave*NB + j -> (slot row = octet*NP + part, 64-column half).  The weights are
+    // stored tap-major (k = tap * Cin + ci): k-tile (cb, tap) is tile index tap * cpb + cb. ----
     const char* b_ptr[NB];
-    int64_t b_step[NB];
+    int64_t b_tile[NB];   // bytes between consecutive weight k-tiles (0 for out-of-range columns -> zero page)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int c = wave * NB + j;
         const int srow = c / (BN / 64), half = c % (BN / 64);
         const int col = n0 + half * 64 + lane;
         const bool ok = col < p.Npad;
-        b_ptr[j] = ok ? wbase + (((int64_t)kt0 * 12 + srow) * p.Npad + col) * 16 : zero;
-        b_step[j] = ok ? (int64_t)12 * p.Npad * 16 : 0;
+        b_tile[j] = ok ? (int64_t)4 * NP * p.Npad * 16 : 0;
+        const int tile0 = (t_kh * d.KW + t_kw) * cpb + t_cb;
+        b_ptr[j] = ok ? wbase + (((int64_t)tile0 * 4 * NP + srow) * p.Npad + col) * 16 : zero;
     }
 
     using gptr_t = const __attribute__((address_space(1))) void*;
@@ -164,32 +186,50 @@ void igemm_dma_kernel(const IgemmK p) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NP; ++q) {
                 const char* src = (ALDM_DMA_ABLATE & 1) ? zero + lane * 16 : a_ptr[i] + q * 64;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + ((wave * RA + i) * 3 + q) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + ((wave * RA + i) * NP + q) * 64), 16, 0, 0);
             }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int c = wave * NB + j;
             const int srow = c / (BN / 64), half = c % (BN / 64);
             const char* src = (ALDM_DMA_ABLATE & 2) ? zero + lane * 16 : b_ptr[j];
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + BM * 12 + srow * BN + half * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + BM * 4 * NP + srow * BN + half * 64), 16, 0, 0);
         }
     };
     // ... and advances the gather state to the k-tile after it
     auto advance = [&]() {
+        if (taps == 1 || !ALDM_DMA_TAP_INNER) {
+            // the next channel block of the same pixels (rows on the zero page keep reading it)
 #pragma unroll
-        for (int i = 0; i < RA; ++i) a_ptr[i] += a_step[i];
+            for (int i = 0; i < RA; ++i) a_ptr[i] += a_step[i];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b_ptr[j] += b_step[j];
-        if (++t_cb == cpb) {   // next tile starts another tap: new row pointers
-            t_cb = 0;
-            if (++t_kw == d.KW) {
-                t_kw = 0;
-                ++t_kh;
+            for (int j = 0; j < NB; ++j) b_ptr[j] += b_tile[j];
+            if (++t_cb == cpb && taps > 1) {   // next tile starts another tap: new row pointers
+                t_cb = 0;
+                if (++t_kw == d.KW) {
+                    t_kw = 0;
+                    ++t_kh;
+                }
+                set_tap();
             }
-            set_tap();
+            return;
         }
+        if (++t_kw == d.KW) {
+            t_kw = 0;
+            ++t_kh;
+        }
+        if (t_kh == d.KH) {   // all taps of this channel block done: first tap of the next block
+            t_kh = 0;
+            ++t_cb;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) b_ptr[j] += b_tile[j] * (1 - (int64_t)(taps - 1) * cpb);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) b_ptr[j] += b_tile[j] * cpb;
+        }
+        set_tap();
     };
     auto issue = [&](int st) {
         issue_dma(st);
@@ -198,7 +238,7 @@ void igemm_dma_kernel(const IgemmK p) {
 
     // fragments of one 16-wide k-step: lane half lh owns k-octet 2*step + lh of both operands
     struct Frag {
-        bf16x8 a[MT][3], b[NT][3];
+        bf16x8 a[MT][NP], b[NT][NP];
     };
     const int a_sw = (l31 >> 2) & 3;
     auto read_frags = [&](Frag& f, int st, int step) {
@@ -211,14 +251,14 @@ void igemm_dma_kernel(const IgemmK p) {
         for (int i = 0; i < MT; ++i) {
             const int row = (wm * MT + i) * 32 + l31;
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                f.a[i][q] = __builtin_bit_cast(bf16x8, sa[((row >> 4) * 3 + q) * 64 + (row & 15) * 4 + (o ^ a_sw)]);
+            for (int q = 0; q < NP; ++q)
+                f.a[i][q] = __builtin_bit_cast(bf16x8, sa[((row >> 4) * NP + q) * 64 + (row & 15) * 4 + (o ^ a_sw)]);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                f.b[j][q] = __builtin_bit_cast(bf16x8, sa[BM * 12 + (o * 3 + q) * BN + (wn * NT + j) * 32 + l31]);
+            for (int q = 0; q < NP; ++q)
+                f.b[j][q] = __builtin_bit_cast(bf16x8, sa[BM * 4 * NP + (o * NP + q) * BN + (wn * NT + j) * 32 + l31]);
     };
 
     f32x16 acc[MT][NT];
@@ -229,20 +269,22 @@ void igemm_dma_kernel(const IgemmK p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     auto mma_frags = [&](const Frag& f) {
-        constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};   // smallest partial products first
+        // smallest partial products first; NP = 2 uses the first three of {mid*hi, hi*mid, hi*hi}
+        constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
+        constexpr int PB_[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
 #if ALDM_DMA_ABLATE & 4
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.a[i][q]));
+            for (int q = 0; q < NP; ++q) asm volatile("" ::"v"(f.a[i][q]));
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) asm volatile("" ::"v"(f.b[j][q]));
+            for (int q = 0; q < NP; ++q) asm volatile("" ::"v"(f.b[j][q]));
         return;
 #endif
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < NPROD; ++q)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -265,7 +307,7 @@ void igemm_dma_kernel(const IgemmK p) {
     __builtin_amdgcn_s_barrier();
     Frag f0, f1;
 #if ALDM_DMA_ABLATE & 8
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NP; ++q) {
         for (int i = 0; i < MT; ++i) f0.a[i][q] = f1.a[i][q] = __builtin_bit_cast(bf16x8, smem[lane + q]);
         for (int j = 0; j < NT; ++j) f0.b[j][q] = f1.b[j][q] = __builtin_bit_cast(bf16x8, smem[lane + 64 + q]);
     }
@@ -278,7 +320,7 @@ void igemm_dma_kernel(const IgemmK p) {
     // merges its LDS counters to lgkmcnt(0), i.e. the fresh reads would be waited for before the first MFMA).
     auto body = [&](auto steady) {
         constexpr bool ST = decltype(steady)::value;
-        constexpr int NMF = 6 * MT * NT, NRD = 3 * (MT + NT);
+        constexpr int NMF = NPROD * MT * NT, NRD = NP * (MT + NT);
         read_frags(f1, st, 1);
         mma_frags(f0);
 #pragma unroll

@@ -4,29 +4,46 @@
 
 namespace aldm {
 
-bool igemm_dma_config_ok(int BM, int BN, int nst) {
-    if (BM == 256 && BN == 128) return nst == 2;
-    if (BM == 128 && BN == 128) return nst == 2 || nst == 3;
+// (tile, ring depth) instantiations; the 2-part ("bf16x3") images are 2/3 the size, so their rings can be deeper
+bool igemm_dma_config_ok(int BM, int BN, int nst, int parts) {
+    if (BM == 256 && BN == 128) return parts == 3 ? nst == 2 : (nst == 2 || nst == 3);
+    if (BM == 128 && BN == 128) return parts == 3 ? (nst == 2 || nst == 3) : (nst == 2 || nst == 4);
     if ((BM == 64 && BN == 128) || (BM == 128 && BN == 64)) return nst == 2 || nst == 4;
     if (BM == 64 && BN == 64) return nst == 2 || nst == 3;
     return false;
 }
 
-int igemm_launch_dma(int BM, int BN, int nst, dim3 grid, hipStream_t st, const IgemmK& p) {
-#define ALDM_DMA(BM_, BN_, NST_) \
-    hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_>), grid, dim3(256), 0, st, p)
-    if (BM == 256 && BN == 128 && nst == 2)
-        hipLaunchKernelGGL((igemm_dma_kernel<256, 128, 2, 4>), grid, dim3(512), 0, st, p);
-    else if (BM == 128 && BN == 128 && nst == 3) ALDM_DMA(128, 128, 3);
-    else if (BM == 128 && BN == 128 && nst == 2) ALDM_DMA(128, 128, 2);
-    else if (BM == 64 && BN == 128 && nst == 4) ALDM_DMA(64, 128, 4);
-    else if (BM == 64 && BN == 128 && nst == 2) ALDM_DMA(64, 128, 2);
-    else if (BM == 128 && BN == 64 && nst == 4) ALDM_DMA(128, 64, 4);
-    else if (BM == 128 && BN == 64 && nst == 2) ALDM_DMA(128, 64, 2);
-    else if (BM == 64 && BN == 64 && nst == 3) ALDM_DMA(64, 64, 3);
-    else if (BM == 64 && BN == 64 && nst == 2) ALDM_DMA(64, 64, 2);
-    else return -1;
+int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+#define ALDM_DMA(BM_, BN_, NST_, NP_) \
+    hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 2, NP_>), grid, dim3(256), 0, st, p)
+#define ALDM_DMA8(BM_, BN_, NST_, NP_) \
+    hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 4, NP_>), grid, dim3(512), 0, st, p)
+    if (parts == 3) {
+        if (BM == 256 && BN == 128 && nst == 2) ALDM_DMA8(256, 128, 2, 3);
+        else if (BM == 128 && BN == 128 && nst == 3) ALDM_DMA(128, 128, 3, 3);
+        else if (BM == 128 && BN == 128 && nst == 2) ALDM_DMA(128, 128, 2, 3);
+        else if (BM == 64 && BN == 128 && nst == 4) ALDM_DMA(64, 128, 4, 3);
+        else if (BM == 64 && BN == 128 && nst == 2) ALDM_DMA(64, 128, 2, 3);
+        else if (BM == 128 && BN == 64 && nst == 4) ALDM_DMA(128, 64, 4, 3);
+        else if (BM == 128 && BN == 64 && nst == 2) ALDM_DMA(128, 64, 2, 3);
+        else if (BM == 64 && BN == 64 && nst == 3) ALDM_DMA(64, 64, 3, 3);
+        else if (BM == 64 && BN == 64 && nst == 2) ALDM_DMA(64, 64, 2, 3);
+        else return -1;
+    } else {
+        if (BM == 256 && BN == 128 && nst == 3) ALDM_DMA8(256, 128, 3, 2);
+        else if (BM == 256 && BN == 128 && nst == 2) ALDM_DMA8(256, 128, 2, 2);
+        else if (BM == 128 && BN == 128 && nst == 4) ALDM_DMA(128, 128, 4, 2);
+        else if (BM == 128 && BN == 128 && nst == 2) ALDM_DMA(128, 128, 2, 2);
+        else if (BM == 64 && BN == 128 && nst == 4) ALDM_DMA(64, 128, 4, 2);
+        else if (BM == 64 && BN == 128 && nst == 2) ALDM_DMA(64, 128, 2, 2);
+        else if (BM == 128 && BN == 64 && nst == 4) ALDM_DMA(128, 64, 4, 2);
+        else if (BM == 128 && BN == 64 && nst == 2) ALDM_DMA(128, 64, 2, 2);
+        else if (BM == 64 && BN == 64 && nst == 3) ALDM_DMA(64, 64, 3, 2);
+        else if (BM == 64 && BN == 64 && nst == 2) ALDM_DMA(64, 64, 2, 2);
+        else return -1;
+    }
 #undef ALDM_DMA
+#undef ALDM_DMA8
     return 0;
 }
 
@@ -40,7 +57,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                                                          int C1, int C2, int64_t rows, int P,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, char* __restrict__ dst,
-                                                         char* __restrict__ dst_raw) {
+                                                         char* __restrict__ dst_raw, int parts) {
     const int C = C1 + C2;
     const int C8 = C >> 3;
     const int64_t total = rows * C8;
@@ -50,14 +67,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         const float* src = c < C1 ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);
         f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
         f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-        const int64_t off = (row * (C >> 5) + (c >> 5)) * SPLIT_BLOCK_BYTES + (c & 31) * 2;
+        const int64_t off = (row * (C >> 5) + (c >> 5)) * (64 * parts) + (c & 31) * 2;
         u32x2 p0[3], p1[3];
         if (dst_raw) {
-            split4(v0, p0);
-            split4(v1, p1);
+            split4_parts(v0, p0, parts);
+            split4_parts(v1, p1, parts);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                *reinterpret_cast<u32x4*>(dst_raw + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+                if (q < parts) *reinterpret_cast<u32x4*>(dst_raw + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
         }
         if constexpr (AFF) {
             const int64_t so = (row / P) * C + c;
@@ -76,11 +93,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                 v1[e] = silu_fast(v1[e]);
             }
         }
-        split4(v0, p0);
-        split4(v1, p1);
+        split4_parts(v0, p0, parts);
+        split4_parts(v1, p1, parts);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            *reinterpret_cast<u32x4*>(dst + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+            if (q < parts) *reinterpret_cast<u32x4*>(dst + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
     }
 }
 
@@ -88,13 +105,13 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 
 using namespace aldm;
 
-extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C) { return rows * (int64_t)(C / 32) * SPLIT_BLOCK_BYTES; }
+extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C, int parts) { return rows * (int64_t)(C / 32) * 64 * parts; }
 
 extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
-                               const float* shift, int act, void* dst, void* dst_raw, void* stream) {
+                               const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream) {
     if (!x2) C2 = 0;
     const int C = C1 + C2;
-    ALDM_CHECK(x1 && dst && rows > 0 && P > 0, "aldm_split_rows: bad args");
+    ALDM_CHECK(x1 && dst && rows > 0 && P > 0 && (parts == 2 || parts == 3), "aldm_split_rows: bad args");
     ALDM_CHECK(C % 32 == 0 && C1 % 8 == 0 && C2 % 8 == 0, "aldm_split_rows: need (C1+C2) %% 32 == 0, C1 %% 8 == 0 (C1=%d C2=%d)",
                C1, C2);
     ALDM_CHECK((scale == nullptr) == (shift == nullptr), "aldm_split_rows: scale/shift must come together");
@@ -108,7 +125,7 @@ extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2,
     hipStream_t st = (hipStream_t)stream;
 #define ALDM_SPLIT(A_, F_)                                                                                        \
     hipLaunchKernelGGL((split_rows_kernel<A_, F_>), dim3(blocks), dim3(256), 0, st, x1, x2, C1, C2, rows, P, scale, \
-                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw))
+                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw), parts)
     if (scale) {
         if (act == ALDM_ACT_SILU) ALDM_SPLIT(ALDM_ACT_SILU, true);
         else ALDM_SPLIT(ALDM_ACT_NONE, true);

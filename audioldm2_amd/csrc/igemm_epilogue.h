@@ -35,7 +35,14 @@ __device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return _
 // that one 32-channel block of one row is 192 contiguous bytes:
 //     img[row][C/32][part 0..2][32]  bf16          (SPLIT_BLOCK_BYTES per (row, 32-channel block))
 // One 16-byte piece = 8 consecutive channels of one part = one MFMA operand fragment of one lane.
-constexpr int SPLIT_BLOCK_BYTES = 192;
+// A 2-part image ("bf16x3" mode) keeps hi + mid only, both ROUNDED TO NEAREST (hi = RN_bf16(x), mid = RN_bf16(x - hi)):
+// |x - hi - mid| <= 2^-16 |x| (2^-18 rms), unbiased; 128 bytes per block.
+constexpr int SPLIT_BLOCK_BYTES = 192;   // 3-part image; a P-part image has 64 * P
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {   // bf16 bit pattern (in the upper half), round to nearest even
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
 
 // exact 3-way split of 4 values -> per part two dwords (4 bf16)
 __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&part)[3]) {
@@ -54,13 +61,33 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&part)[3]) {
     part[2] = u32x2{hi16_pair(u2[0], u2[1]), hi16_pair(u2[2], u2[3])};
 }
 
-// channels c .. c+3 (c % 4 == 0) of row `row` of a split image with Cs channels per row
-__device__ __forceinline__ void split_store4(void* img, int64_t row, int Cs, int c, const f32x4 v) {
-    u32x2 part[3];
-    split4(v, part);
-    char* base = reinterpret_cast<char*>(img) + (row * (Cs >> 5) + (c >> 5)) * SPLIT_BLOCK_BYTES + (c & 31) * 2;
+// 2-part split (hi, mid), round to nearest
+__device__ __forceinline__ void split4_rn2(const f32x4 v, u32x2 (&part)[3]) {
+    unsigned u0[4], u1[4];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(base + q * 64) = part[q];
+    for (int c = 0; c < 4; ++c) {
+        const float x = v[c];
+        u0[c] = bf16_rn_bits(x);
+        u1[c] = bf16_rn_bits(x - __builtin_bit_cast(float, u0[c]));
+    }
+    part[0] = u32x2{hi16_pair(u0[0], u0[1]), hi16_pair(u0[2], u0[3])};
+    part[1] = u32x2{hi16_pair(u1[0], u1[1]), hi16_pair(u1[2], u1[3])};
+    part[2] = u32x2{0u, 0u};
+}
+
+__device__ __forceinline__ void split4_parts(const f32x4 v, u32x2 (&part)[3], int parts) {
+    if (parts == 2) split4_rn2(v, part);
+    else split4(v, part);
+}
+
+// channels c .. c+3 (c % 4 == 0) of row `row` of a split image with Cs channels per row and `parts` parts
+__device__ __forceinline__ void split_store4(void* img, int64_t row, int Cs, int c, const f32x4 v, int parts = 3) {
+    u32x2 part[3];
+    split4_parts(v, part, parts);
+    char* base = reinterpret_cast<char*>(img) + (row * (Cs >> 5) + (c >> 5)) * (64 * parts) + (c & 31) * 2;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < parts) *reinterpret_cast<u32x2*>(base + q * 64) = part[q];
 }
 
 // one output element through the fused epilogue (split-K reduce and ragged-N fallbacks)
@@ -146,7 +173,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                     const int m = m0 + (wm * MT + i) * 32 + r;
                     if (m < p.M && cok) {
                         if (go) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;
-                        if (simg) split_store4(simg, m, d.out_split_c, ncol_o, xv);
+                        if (simg) split_store4(simg, m, d.out_split_c, ncol_o, xv, d.split_parts);
                     }
                 }
             }
@@ -250,7 +277,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
             if (simg) {  // second output: the result as a split image (host checks N % 4 == 0, vec)
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
-                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], d.out_split_c, ncol, v[it]);
+                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], d.out_split_c, ncol, v[it], d.split_parts);
             }
         } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
 #pragma unroll

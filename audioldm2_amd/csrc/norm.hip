@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ y, int M, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        void* __restrict__ y_split) {
+                                                        void* __restrict__ y_split, int parts) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (c4 < C4) {
                 const f32x4 o = (v[r][i] - mean[r]) * rstd[r] * ga[i] + be[i];
                 if (yr) *reinterpret_cast<f32x4*>(yr + 4 * c4) = o;
-                if (y_split) split_store4(y_split, row0 + r, C, 4 * c4, o);   // the next GEMM's pre-split A operand
+                if (y_split) split_store4(y_split, row0 + r, C, 4 * c4, o, parts);   // the next GEMM's pre-split A operand
             }
         }
     }
@@ -369,8 +369,9 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
     return 0;
 }
 
-static int layernorm_launch(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
+static int layernorm_launch(const float* x, float* y, void* y_split, int parts, int M, int C, const float* gamma,
                             const float* beta, float eps, void* stream, const char* name) {
+    ALDM_CHECK(parts == 2 || parts == 3, "%s: parts must be 2 or 3", name);
     ALDM_CHECK(x && (y || y_split) && gamma && beta, "%s: null pointer", name);
     ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "%s: C=%d must be a multiple of 4 and <= %d", name, C, 256 * LN_MAXV);
     ALDM_CHECK(y_split == nullptr || (C % 32 == 0 && (reinterpret_cast<uintptr_t>(y_split) & 15) == 0),
@@ -378,7 +379,7 @@ static int layernorm_launch(const float* x, float* y, void* y_split, int M, int 
     hipStream_t st = (hipStream_t)stream;
 #define ALDM_LN(V_, R_)                                                                                  \
     hipLaunchKernelGGL((layernorm_kernel<V_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, C, \
-                       gamma, beta, eps, y_split)
+                       gamma, beta, eps, y_split, parts)
     const int nv = cdiv(C / 4, 64);
     if (nv <= 1) ALDM_LN(1, 4);
     else if (nv <= 2) ALDM_LN(2, 4);
@@ -391,12 +392,12 @@ static int layernorm_launch(const float* x, float* y, void* y_split, int M, int 
 
 extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                               const float* beta, float eps, void* stream) {
-    return layernorm_launch(x, y, nullptr, M, C, gamma, beta, eps, stream, "aldm_layernorm");
+    return layernorm_launch(x, y, nullptr, 3, M, C, gamma, beta, eps, stream, "aldm_layernorm");
 }
 
 extern "C" int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
-                                    const float* beta, float eps, void* stream) {
-    return layernorm_launch(x, y, y_split, M, C, gamma, beta, eps, stream, "aldm_layernorm_split");
+                                    const float* beta, float eps, int parts, void* stream) {
+    return layernorm_launch(x, y, y_split, parts, M, C, gamma, beta, eps, stream, "aldm_layernorm_split");
 }
 
 extern "C" int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale,

@@ -45,7 +45,7 @@ class IgemmDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("hint_bm", C.c_int32), ("hint_bn", C.c_int32), ("hint_splits", C.c_int32), ("hint_kgroups", C.c_int32),
         ("w_split", C.c_void_p), ("hint_mma", C.c_int32), ("hint_stages", C.c_int32),
-        ("a_split", C.c_void_p), ("out_split", C.c_void_p), ("out_split_c", C.c_int32), ("reserved0", C.c_int32),
+        ("a_split", C.c_void_p), ("out_split", C.c_void_p), ("out_split_c", C.c_int32), ("split_parts", C.c_int32),
     ]
 
 
@@ -57,17 +57,20 @@ _SIGS = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
     "aldm_igemm_ws_floats": (C.c_int64, [C.POINTER(IgemmDesc)]),
+    "aldm_igemm_plan_stages": (C.c_int, [C.POINTER(IgemmDesc)]),
     "aldm_igemm_force": (None, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "aldm_igemm_force_stages": (None, [C.c_int]),
     "aldm_igemm_wave8_mask": (C.c_int, [C.c_int]),
-    "aldm_split_image_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "aldm_split_image_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "aldm_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
-                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_layernorm_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                       C.c_float, C.c_void_p]),
-    "aldm_attention_d32_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_float, C.c_int, C.c_void_p]),
+    "aldm_attention_d32_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_float, C.c_void_p]),
+    "aldm_split_bytes_parts": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "aldm_pack_split_bf16_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_igemm_mma": (C.c_int, [C.c_int]),
     "aldm_split_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "aldm_pack_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -85,6 +88,10 @@ _SIGS = {
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_float, C.c_void_p]),
+    "aldm_rel_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p]),
+    "aldm_rowscale_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "aldm_softmax_rows_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                            C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
@@ -114,6 +121,21 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
 
 _lib = None
+
+
+def source_hash() -> str:
+    """16 hex digits over the kernel sources and the ABI header: profile artefacts (profiles/*.json) carry it so a
+    reader — and bench.py — can tell whether they describe the code that is running."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load():

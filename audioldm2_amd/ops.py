@@ -32,21 +32,34 @@ def _chk(t: torch.Tensor, name: str):
                            f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
-# Matrix-core path of the igemm engine: "f32" = fp32 MFMA (v_mfma_f32_32x32x2_f32), "bf16x6" = fp32 product as
-# 6 bf16 partial products of exact 3-way operand splits on the bf16 matrix cores, fp32 accumulate (fp32-grade
-# error) - the default: 1.3-1.8x the fp32 MFMA's throughput at the same accuracy.  $ALDM_MMA
-# overrides; set_mma() switches at run time (packed weights build their split image lazily on first use).
-MMA_MODE = os.environ.get("ALDM_MMA", "bf16x6")
-assert MMA_MODE in ("f32", "bf16x6"), MMA_MODE
+# Matrix-core path of the igemm engine ($ALDM_MMA overrides; set_mma() switches at run time; packed weights build their
+# split images lazily on first use).  Operands, accumulation and every stored tensor are fp32 in all three:
+#   "f32"     fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, 1/16 of the bf16 matrix rate;
+#   "bf16x6"  every fp32 product as 6 bf16 partial products of exact 3-way operand splits: fp32-grade (error vs fp64
+#             2.4e-7 rms, the fp32 MFMA's 2.1e-7), the strict mode;
+#   "bf16x3"  the DEFAULT since round 2: the DMA-fed GEMMs (pre-split operands, csrc/igemm_dma.h) keep two parts per operand,
+#             (hi, mid) rounded to nearest = 16 significant bits, and evaluate hi*hi + hi*mid + mid*hi — half the
+#             matrix-pipe work (the chip is POWER limited on this instruction mix: tools/mfma_peak.py) and 2/3 of the operand
+#             bytes.  Per-GEMM error 4.4e-6 rms vs fp64 (plain bf16: 2.9e-3; tools/x3_accuracy.py); the 200-step waveform
+#             matches the reference to 2.0e-8 rms — the same as bf16x6 (1.9e-8) and 50 000x inside north_star's 1e-3
+#             (profiles/r02_parity_report.txt).  Launches without a pre-split operand (VAE, vocoder, STFT, ragged shapes)
+#             run "bf16x6".
+MMA_MODE = os.environ.get("ALDM_MMA", "bf16x3")
+assert MMA_MODE in ("f32", "bf16x6", "bf16x3"), MMA_MODE
 
 
 def set_mma(mode: str) -> str:
-    """Select the matrix-core path for subsequent igemm launches ("f32" | "bf16x6"); returns the previous one.
-    Captured HIP graphs keep the path they were captured with."""
+    """Select the matrix-core path for subsequent igemm launches ("f32" | "bf16x6" | "bf16x3"); returns the previous
+    one.  Captured HIP graphs keep the path they were captured with."""
     global MMA_MODE
-    assert mode in ("f32", "bf16x6"), mode
+    assert mode in ("f32", "bf16x6", "bf16x3"), mode
     prev, MMA_MODE = MMA_MODE, mode
     return prev
+
+
+def split_parts() -> int:
+    """Parts per operand of the split images the current mode produces / consumes."""
+    return 2 if MMA_MODE == "bf16x3" else 3
 
 
 @dataclass
@@ -60,15 +73,26 @@ class Packed:
     KW: int
     bias: Optional[torch.Tensor] = None
     split: Optional[torch.Tensor] = None
+    split2: Optional[torch.Tensor] = None   # the 2-part ("bf16x3") image, DMA-fed launches only
 
     @property
     def K(self) -> int:
         return self.KH * self.KW * self.Cin
 
-    def split_ptr(self) -> Optional[int]:
-        """Device pointer of the bf16-split image (built on first use) or None in fp32 mode."""
-        if MMA_MODE != "bf16x6":
+    def split_ptr(self, parts: int = 3) -> Optional[int]:
+        """Device pointer of the bf16-split image with `parts` parts (built on first use) or None in fp32 mode."""
+        if MMA_MODE == "f32":
             return None
+        if parts == 2:
+            if self.split2 is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("a weight's 2-part split image must exist before graph capture (run one eager step)")
+                lib = _l.load()
+                self.split2 = torch.empty(lib.aldm_split_bytes_parts(self.K, self.N, 2) // 4, device=self.data.device,
+                                          dtype=torch.int32)
+                _l.check(lib.aldm_pack_split_bf16_parts(self.data.data_ptr(), self.split2.data_ptr(), self.K, self.N, 2,
+                                                        _stream()), "pack_split_bf16(2)")
+            return self.split2.data_ptr()
         if self.split is None:
             if torch.cuda.is_current_stream_capturing():
                 return None  # never allocate inside a capture: this launch stays on the fp32 MFMA
@@ -89,14 +113,18 @@ class SplitT:
         self.data = data
         self.shape = tuple(shape)
 
+    @property
+    def parts(self) -> int:
+        return self.data.shape[2]
+
     @staticmethod
-    def empty(shape, device) -> "SplitT":
+    def empty(shape, device, parts: Optional[int] = None) -> "SplitT":
         C_ = shape[-1]
         assert C_ % 32 == 0, f"split image needs C % 32 == 0, got {C_}"
         rows = 1
         for s_ in shape[:-1]:
             rows *= s_
-        return SplitT(torch.empty((rows, C_ // 32, 3, 32), device=device, dtype=torch.int16), shape)
+        return SplitT(torch.empty((rows, C_ // 32, parts or split_parts(), 32), device=device, dtype=torch.int16), shape)
 
     @property
     def C(self) -> int:
@@ -126,7 +154,10 @@ class SplitT:
     def float(self) -> torch.Tensor:
         """hi + mid + lo back to fp32 (tests / debugging): exact."""
         parts = (self.data.to(torch.int32) << 16).view(torch.float32)
-        return (parts[:, :, 0] + parts[:, :, 1] + parts[:, :, 2]).reshape(self.shape)
+        acc = parts[:, :, 0] + parts[:, :, 1]
+        if self.parts == 3:
+            acc = acc + parts[:, :, 2]
+        return acc.reshape(self.shape)
 
 
 # DMA-fed GEMM path (pre-split activations, csrc/igemm_dma.h): on by default in "bf16x6" mode; ALDM_DMA=0 / set_dma(False)
@@ -141,7 +172,7 @@ def set_dma(on: bool) -> bool:
 
 
 def use_dma() -> bool:
-    return DMA_MODE and MMA_MODE == "bf16x6"
+    return DMA_MODE and MMA_MODE in ("bf16x6", "bf16x3")
 
 
 def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act: int = ACT_NONE,
@@ -165,7 +196,7 @@ def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act
         sc, sh = pre
         assert sc.shape == (x.shape[0], C1 + C2) and sc.is_contiguous() and sh.is_contiguous()
     _l.check(_l.load().aldm_split_rows(x.data_ptr(), _p(x2), C1, C2, rows, P, _p(sc), _p(sh), act, dst.data_ptr(),
-                                       None if raw is None else raw.data_ptr(), _stream()), "split_rows")
+                                       None if raw is None else raw.data_ptr(), dst.parts, _stream()), "split_rows")
     return (dst, raw) if want_raw else dst
 
 
@@ -214,7 +245,8 @@ TUNE_LOG = None  # when a list: every launch's geometry key is appended (tools/i
 def tune_key(d: IgemmDesc) -> str:
     """Geometry key of a launch (tuned tables, TUNE_LOG); DMA-fed launches (pre-split A operand) carry a ",dma" suffix:
     they have their own kernel family and table."""
-    return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}" + (",dma" if d.a_split else "")
+    return ",".join(str(getattr(d, f)) for f in _TUNE_FIELDS) + f",{_pre_mode(d)}" + \
+        (("," + ("dma2" if d.split_parts == 2 else "dma")) if d.a_split else "")
 
 
 def _tuned_table(bx=False):
@@ -222,10 +254,10 @@ def _tuned_table(bx=False):
     bx="dma": {key: [BM, BN, splits, stages]} for the DMA-fed kernel."""
     global _TUNED
     if _TUNED is None:
-        _TUNED = {False: {}, True: {}, "dma": {}}
+        _TUNED = {False: {}, True: {}, "dma": {}, "dma2": {}}
         if os.environ.get("ALDM_NO_TUNING", "0") != "1":
             for mode, name in ((False, "mi355x_igemm.json"), (True, "mi355x_igemm_bf16x6.json"),
-                               ("dma", "mi355x_igemm_dma.json")):
+                               ("dma", "mi355x_igemm_dma.json"), ("dma2", "mi355x_igemm_dma_bf16x3.json")):
                 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", name)
                 if os.path.exists(path):
                     with open(path) as f:
@@ -239,7 +271,7 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     if TUNE_LOG is not None:
         TUNE_LOG.append(key)
     if d.a_split:
-        hint = _tuned_table("dma").get(key)
+        hint = _tuned_table("dma2" if d.split_parts == 2 else "dma").get(key)
         if hint is not None:
             d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = hint[:4]
     else:
@@ -260,7 +292,7 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
     e1.record()
     shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch,
-             sp.value * 10 + kg.value)
+             sp.value * 10 + kg.value, int(bool(d.a_split)), int(bool(d.out)), int(bool(d.out_split)))
     PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape,
                     _kernel_name(d, bm.value, bn.value, kg.value, bool(mma.value))))
 
@@ -282,7 +314,8 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
     if d.a_split:
-        return f"igemm_dma_kernel<{bm}, {bn}>"
+        return (f"igemm_dma_kernel<{bm}, {bn}, {_l.load().aldm_igemm_plan_stages(C.byref(d))}, {4 if bm == 256 else 2}, "
+                f"{d.split_parts or 3}>")
     pre = _pre_mode(d)
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     # 8 waves per tile: same rule as csrc/igemm.hip (ALDM_IGEMM_W8 tile mask, default 128x128 GroupNorm prologues)
@@ -378,13 +411,17 @@ def linear_geglu(x, pw: Packed, split_out: Optional[str] = None):
     so = SplitT.empty(oshape, x.device) if split_out else None
     d = IgemmDesc()
     if is_split:
-        d.a_split = x.data_ptr()
+        d.a_split = x.data_ptr(); d.split_parts = x.parts
     else:
-        d.x1 = x.data_ptr()
+        d.x1 = x.data_ptr(); d.split_parts = 3
+    assert so is None or so.parts == d.split_parts or not is_split
+    if so is not None and not is_split:
+        d.split_parts = so.parts
     d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
-    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N; d.w_split = pw.split_ptr()
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
+    d.w_split = pw.split_ptr(x.parts if is_split else 3)
     d.bias = _p(pw.bias); d.out = _p(out); d.ldo = pw.N // 2; d.alpha = 1.0
     if so is not None:
         d.out_split = so.data_ptr(); d.out_split_c = pw.N // 2
@@ -460,9 +497,9 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
         bias = pw.bias
     d = IgemmDesc()
     if is_split:
-        d.a_split = x.data_ptr()
+        d.a_split = x.data_ptr(); d.split_parts = x.parts
     else:
-        d.x1 = x.data_ptr()
+        d.x1 = x.data_ptr(); d.split_parts = so.parts if so is not None else 3
     d.x2 = _p(x2)
     d.C1 = C1; d.C2 = C2; d.pix1 = 0; d.pix2 = 0
     d.B = B; d.H = H; d.W = W; d.up_h = up[0]; d.up_w = up[1]
@@ -472,7 +509,10 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     if pre is not None:
         d.pre_scale = pre[0].data_ptr(); d.pre_shift = pre[1].data_ptr()
     d.pre_act = pre_act; d.pre_slope = pre_slope
-    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0; d.w_split = pw.split_ptr()
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
+    # register-staged launches always use the 3-part weight image; a 2-part out_split from them needs split_parts = 2,
+    # which rules the bf16-split register-staged kernel out (fp32 MFMA then): only DMA-fed launches write 2-part images
+    d.w_split = pw.split_ptr(x.parts if is_split else 3)
     d.K = pw.K; d.N = N
     d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = _p(out)
     if so is not None:
@@ -603,7 +643,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         return y
     so = SplitT.empty(x.shape, x.device)
     _l.check(_l.load().aldm_layernorm_split(x.data_ptr(), _p(y), so.data_ptr(), M, Cc, gamma.data_ptr(),
-                                            beta.data_ptr(), eps, _stream()), "layernorm_split")
+                                            beta.data_ptr(), eps, so.parts, _stream()), "layernorm_split")
     return so if split_out == "only" else (y, so)
 
 
@@ -635,9 +675,43 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *,
                                               heads * 32, _p(mask), scale, _stream()), "attention_d32")
         return out
     so = SplitT.empty((B, Lq, heads * 32), q.device)
-    _l.check(_l.load().aldm_attention_d32_split(qp, kp, vp, _p(out), so.data_ptr(), B, heads, Lq, Lk, ldq, ldk, ldv,
-                                                heads * 32, _p(mask), scale, _stream()), "attention_d32_split")
+    _l.check(_l.load().aldm_attention_d32_split(qp, kp, vp, _p(out), so.data_ptr(), so.parts, B, heads, Lq, Lk, ldq, ldk,
+                                                ldv, heads * 32, _p(mask), scale, _stream()), "attention_d32_split")
     return so if split_out == "only" else (out, so)
+
+
+def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, emb_k: torch.Tensor, emb_v: torch.Tensor,
+                  mask: torch.Tensor) -> torch.Tensor:
+    """Windowed relative-position self-attention (VITS phoneme encoder, attentions.py:239-289).  q/k/v: [B, T, heads*d]
+    views; emb_k / emb_v: [2*window+1, d]; mask [B, T] floats (1 = token)."""
+    qp, T, ldq = _rowview(q, "rel_attn.q")
+    kp, Tk, ldk = _rowview(k, "rel_attn.k")
+    vp, Tv, ldv = _rowview(v, "rel_attn.v")
+    B = q.shape[0]
+    d = q.shape[2] // heads
+    assert T == Tk == Tv and emb_k.shape == emb_v.shape and emb_k.shape[1] == d and emb_k.shape[0] % 2 == 1
+    _chk(emb_k, "rel_attn.emb_k"); _chk(emb_v, "rel_attn.emb_v"); _chk(mask, "rel_attn.mask")
+    assert mask.shape == (B, T)
+    out = torch.empty((B, T, heads * d), device=q.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_rel_attention(qp, kp, vp, out.data_ptr(), B, heads, T, d, ldq, ldk, ldv, heads * d,
+                                          emb_k.data_ptr(), emb_v.data_ptr(), emb_k.shape[0] // 2, mask.data_ptr(),
+                                          _stream()), "rel_attention")
+    return out
+
+
+def rowscale_add(x: torch.Tensor, s: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[r, c] = x[r, c] * s[r] (+ res[r, c]); x: [..., C], s: one scale per row."""
+    _chk(x, "rowscale.x"); _chk(s, "rowscale.s")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    assert s.numel() == rows
+    if res is not None:
+        _chk(res, "rowscale.res")
+        assert res.shape == x.shape
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_rowscale_add(x.data_ptr(), s.data_ptr(), _p(res), y.data_ptr(), rows, Cc, _stream()),
+             "rowscale_add")
+    return y
 
 
 def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:

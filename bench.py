@@ -34,7 +34,42 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 # bf16-split kernels ("BF16x6"): one fp32 multiply-add = 6 bf16 MFMA partial products, so their fp32-equivalent
 # matrix-core roofline is the dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, ~2500 TFLOP/s) / 6
 PEAK_BF16X6_TFLOPS = round(2500.0 / 6.0, 1)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+PEAK_BF16X3_TFLOPS = round(2500.0 / 3.0, 1)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+# algorithmic GFLOP per sample of the tail stages (FlopCounterMode on the reference modules)
+VAE_DECODE_GFLOP = {"audioldm2-full": 670.5, "audioldm2-full-large-1150k": 670.5, "audioldm2-speech-gigaspeech": 670.5,
+                    "audioldm_48k": 3480.7}
+HIFIGAN_GFLOP = {"audioldm2-full": 1027.0, "audioldm2-full-large-1150k": 1027.0, "audioldm2-speech-gigaspeech": 1027.0,
+                 "audioldm_48k": 7081.8}
+
+
+def mfma_ceiling():
+    """What the bf16 matrix pipe of THIS chip sustains on the igemm engine's own instruction mix with operands that are
+    split images of random fp32 data and no memory traffic (tools/gpu/mfma_peak.hip, built by __graft_entry__.build()):
+    the chip is power limited there — the core clock sags to ~1.65 GHz — so the nominal 2.5 PFLOP/s (2.4 GHz) cannot
+    be reached by ANY kernel on such data.  Returns {"bf16_tflops", "fp32_equiv_tflops", "core_mhz"} or None."""
+    import ctypes
+    so = os.path.join(ROOT, "tools", "gpu", "libmfma_peak.so")
+    if not os.path.exists(so):
+        return None
+    try:
+        lib = ctypes.CDLL(so)
+        lib.mfma_peak_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_double)]
+        best = None
+        for _ in range(2):
+            tf, mhz = ctypes.c_double(), ctypes.c_double()
+            if lib.mfma_peak_run(1, 20000, 1, ctypes.byref(tf), ctypes.byref(mhz)) == 0:
+                if best is None or tf.value > best[0]:
+                    best = (tf.value, mhz.value)
+        if best is None:
+            return None
+        return {"bf16_tflops": round(best[0], 1), "fp32_equiv_tflops": round(best[0] / 6.0, 1),
+                "core_mhz": round(best[1]),
+                "what": "24 x v_mfma_f32_32x32x16_bf16 per iteration over 4 accumulators in the bf16x6 order, one wave "
+                        "per SIMD on all 256 CUs, operands = split images of uniform random fp32, no memory traffic"}
+    except Exception:  # pragma: no cover
+        return None
 
 
 def parse():
@@ -45,7 +80,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="prompts per GPU")
     ap.add_argument("--ddim-steps", type=int, default=200)
     ap.add_argument("--model", default="audioldm2-full")
-    ap.add_argument("--mma", choices=["bf16x6", "f32"], default=None,
+    ap.add_argument("--mma", choices=["bf16x6", "bf16x3", "f32"], default=None,
                     help="matrix-core path of the igemm engine (default: $ALDM_MMA or the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -79,7 +114,10 @@ def roofline_probe(ld, batch, B):
         a[1] += fl
         a[2] += e0.elapsed_time(e1) * 1e-3
         M, N, K, taps = shape[0], shape[1], shape[2], shape[3]
-        a[3] += 4.0 * (M * K / taps + K * N + M * N) * shape[7]  # read A once + W once, write out once
+        if len(shape) > 9 and shape[9]:  # DMA-fed: A and W are split images (6 B/element), outputs fp32 and / or split
+            a[3] += 6.0 * (M * K / taps + K * N) + M * N * (4.0 * shape[10] + 6.0 * shape[11])
+        else:
+            a[3] += 4.0 * (M * K / taps + K * N + M * N) * shape[7]  # read A once + W once, write out once
     dom = max(agg.items(), key=lambda kv: kv[1][2])
     kname, (n, fl, sec, minb) = dom
     achieved = fl / sec / 1e12
@@ -89,22 +127,35 @@ def roofline_probe(ld, batch, B):
     # command, committed under profiles/ (tools/pmc_traffic.py); null when that file is absent
     traffic, traffic_src = None, None
     if os.path.exists(TRAFFIC_JSON):
+        from audioldm2_amd.lib import source_hash
         with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
         ent = tj.get("kernels", {}).get(kname)
-        if ent:
+        if tj.get("source_hash") != source_hash():
+            # the PMC passes were collected on other kernel sources than the ones running now: not evidence for this line
+            traffic_src = {"file": "profiles/" + os.path.basename(TRAFFIC_JSON), "stale": True,
+                           "file_source_hash": tj.get("source_hash"), "running_source_hash": source_hash()}
+        elif ent:
             traffic = ent["hbm_bytes_per_launch"]
-            traffic_src = {"file": "profiles/r01_pmc_traffic.json", "launches": ent["launches"],
+            traffic_src = {"file": "profiles/" + os.path.basename(TRAFFIC_JSON), "source_hash": tj["source_hash"],
+                           "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}
-    bx = kname.endswith("true>")  # igemm_kernel<..., BX>: bf16-split instantiation
-    peak = PEAK_BF16X6_TFLOPS if bx else PEAK_F32_MFMA_TFLOPS
+    bx = kname.endswith("true>") or kname.startswith("igemm_dma_kernel")  # bf16-split instantiations
+    x3 = kname.startswith("igemm_dma_kernel") and kname.endswith(", 2>")   # NP = 2 instantiation
+    peak = (PEAK_BF16X3_TFLOPS if x3 else PEAK_BF16X6_TFLOPS) if bx else PEAK_F32_MFMA_TFLOPS
+    ceil = mfma_ceiling() if bx else None
+    if ceil and x3:
+        ceil["fp32_equiv_tflops"] = round(ceil["bf16_tflops"] / 3.0, 1)
+    by_kernel = sorted(agg.items(), key=lambda kv: -kv[1][2])[:6]
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4),
-        "peak_note": ("fp32-equivalent peak of the bf16-split kernels: dense bf16 MFMA 2500 TFLOP/s / 6 partial "
-                      "products per fp32 multiply-add" if bx else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+        "peak_note": ((f"fp32-equivalent peak of the bf16-split kernels: dense bf16 MFMA 2500 TFLOP/s / {3 if x3 else 6} "
+                       "partial products per fp32 multiply-add") if bx else "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
         "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "measured_mfma_ceiling": ceil,
+        "frac_of_measured_ceiling": round(achieved / ceil["fp32_equiv_tflops"], 4) if ceil else None,
         "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": round(minb / n),
         "kernel": "aldm::" + kname, "launches_per_unet_pass": n,
@@ -112,7 +163,30 @@ def roofline_probe(ld, batch, B):
         "all_igemm_tflops": round(tot_fl / tot_s / 1e12, 2),
         "all_igemm_launches": sum(v[0] for v in agg.values()),
         "all_igemm_ms": round(tot_s * 1e3, 3),
+        "top_kernels": [{"kernel": k, "launches": v[0], "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1)}
+                        for k, v in by_kernel],
     }
+
+
+def tail_roofline(ld, B, model):
+    """VAE decode and HiFi-GAN of one batch, timed with events on the launch stream: algorithmic TFLOP/s of each stage
+    (SURVEY.md §8(d) FLOPs per sample) against the matrix pipe they run on (the register-staged bf16-split igemm)."""
+    z = torch.randn(B, ld.channels, ld.latent_t_size, ld.latent_f_size, device="cuda")
+    out = {}
+    for _ in range(2):  # first pass packs weights
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        mel = ld.decode_first_stage_cl(z)
+        ev[1].record()
+        ld.first_stage_model.vocoder.forward_cl(mel.view(mel.shape[0], mel.shape[1], mel.shape[2]).float().contiguous())
+        ev[2].record()
+        torch.cuda.synchronize()
+    for name, gf, a, b in (("vae_decode", VAE_DECODE_GFLOP[model], 0, 1), ("hifigan", HIFIGAN_GFLOP[model], 1, 2)):
+        ms = ev[a].elapsed_time(ev[b])
+        tf = gf * B / ms  # GFLOP / ms = TFLOP/s
+        out[name] = {"ms": round(ms, 2), "gflop_per_sample": gf, "achieved": round(tf, 1), "unit": "TFLOP/s",
+                     "peak": PEAK_BF16X6_TFLOPS, "frac": round(tf / PEAK_BF16X6_TFLOPS, 4), "bound": "mfma"}
+    return out
 
 
 def unet_step_probe(ld, batch, B, steps=12):
@@ -144,12 +218,22 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
     from oracle.pipeline import OracleLatentDiffusion
     from oracle.vae import hifigan_forward, vae_decode
     o = OracleLatentDiffusion()
-    threads = torch.get_num_threads()
     batch = cases.e2e_batch(1)
     cond = {k: m(batch if o.cond_stage_key[k] == "all" else batch[o.cond_stage_key[k]]) for k, m in o.cond_models.items()}
     uncond = {k: m.get_unconditional_condition(1) for k, m in o.cond_models.items()}
     torch.manual_seed(0)
-    ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, 5, 1.0, o.buffers["alphas_cumprod"])  # warm (1 step pair x5 is cheap enough)
+    # B = 1 ops are small: oversubscribing all host threads is several times SLOWER than a few, so
+    # the baseline is the best of a sweep, with the winning count reported as `cores`
+    sweep = {}
+    ncpu = os.cpu_count() or 8
+    for th in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(th)
+        ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, 1, 1.0, o.buffers["alphas_cumprod"])  # warm
+        t0 = time.time()
+        ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, 2, 1.0, o.buffers["alphas_cumprod"])
+        sweep[th] = (time.time() - t0) / 2
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     t0 = time.time()
     z = ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, ddim_steps_sample, 1.0, o.buffers["alphas_cumprod"])
     t_loop = time.time() - t0
@@ -162,10 +246,11 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
     step_s = t_loop / ddim_steps_sample
     total = step_s * total_steps + t_dec + t_voc
     return {"value": round((163872 / 16000.0) / total, 5), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": (f"CPU oracle (torch fp32, {threads} threads), B=1: {ddim_steps_sample} DDIM steps timed "
-                       f"({step_s*1e3:.0f} ms/step) x{total_steps} extrapolated + VAE decode {t_dec:.2f}s + "
-                       f"vocoder {t_voc:.2f}s"),
-            "unet_step_ms": round(step_s * 1e3, 1)}
+            "sample": (f"CPU oracle (torch fp32, best of a thread sweep: {threads} of {ncpu} host threads), B=1: "
+                       f"{ddim_steps_sample} DDIM steps timed ({step_s*1e3:.0f} ms/step) x{total_steps} extrapolated + "
+                       f"VAE decode {t_dec:.2f}s + vocoder {t_voc:.2f}s"),
+            "unet_step_ms": round(step_s * 1e3, 1),
+            "thread_sweep_ms_per_step": {str(k): round(v * 1e3) for k, v in sweep.items()}}
 
 
 def main():
@@ -232,8 +317,12 @@ def main():
                                    "sample_log + VAE decode + HiFi-GAN + D2H of the waveform; synthetic "
                                    "conditioning, random-init weights, host-CPU RNG noise",
                        "mma": ("bf16x6: fp32 operands and accumulation, each product evaluated as 6 bf16 MFMA partial "
-                               "products of exact 3-way operand splits (fp32-grade error)" if aops.MMA_MODE == "bf16x6"
-                               else "f32: fp32 MFMA"),
+                               "products of exact 3-way operand splits (fp32-grade error)" +
+                               ("; GEMM operands pre-split by their producers, DMA-fed kernel (igemm_dma.h)"
+                                if aops.use_dma() else "") if aops.MMA_MODE == "bf16x6" else
+                               ("bf16x3: fp32 operands and accumulation; DMA-fed GEMMs keep (hi, mid) of every operand, rounded "
+                                "to nearest (16 significant bits), 3 bf16 MFMA partial products per product; other launches bf16x6"
+                                if aops.MMA_MODE == "bf16x3" else "f32: fp32 MFMA")),
                        "global_batch": gB, "parallelism": f"prompt-sharded replicas x{world}",
                        "weight_broadcast_bytes": bcast_bytes},
         }
@@ -245,10 +334,18 @@ def main():
             gf = UNET_GFLOP_PER_FWD_SAMPLE[args.model]
             out["unet_step_tflops"] = round(2 * gf * B / step_ms, 2)  # GFLOP/ms = TFLOP/s
             out["unet_step_frac_of_f32_mfma_peak"] = round(out["unet_step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+            out["unet_step_frac_of_bf16x6_peak"] = round(out["unet_step_tflops"] / PEAK_BF16X6_TFLOPS, 4)
         except Exception as e:  # pragma: no cover
             out["unet_step_ms"] = f"probe failed: {e}"
         if not args.no_roofline:
             out["roofline"] = roofline_probe(ld, make_batch_for_text_to_audio("synthetic prompt", batchsize=B), B)
+            try:
+                out["roofline_tail"] = tail_roofline(ld, B, args.model)
+            except Exception as e:  # pragma: no cover
+                out["roofline_tail"] = f"probe failed: {e}"
+            ceil = out["roofline"].get("measured_mfma_ceiling")
+            if ceil and isinstance(out.get("unet_step_tflops"), float):
+                out["unet_step_frac_of_measured_ceiling"] = round(out["unet_step_tflops"] / ceil["fp32_equiv_tflops"], 4)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(1, args.cpu_ddim_steps, args.ddim_steps)
         print(json.dumps(out), flush=True)

@@ -139,7 +139,10 @@ typedef struct aldm_igemm_desc {
     const void* a_split;
     void* out_split;
     int32_t out_split_c;
-    int32_t reserved0;
+    int32_t split_parts;   /* parts of a_split, of out_split and of the w_split the DMA-fed kernel reads: 3 (or 0) =
+                              exact 3-way split, 6 partial products ("bf16x6"); 2 = (hi, mid) rounded to nearest, 3
+                              partial products ("bf16x3": ~16 significant bits per operand, unbiased).  The register-
+                              staged kernels always use the 3-part w_split.                                      */
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -153,6 +156,9 @@ int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* d);
  * accounting.  splits / kgroups may be NULL.                                                              */
 int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits, int* kgroups,
                     int* mma);   /* mma: ALDM_MMA_* the launch would run on (may be NULL) */
+/* Host-only query: LDS ring depth of the DMA-fed kernel this descriptor launches (a_split set), 0 for the register-
+ * staged kernels, negative on an invalid descriptor.                                                            */
+int aldm_igemm_plan_stages(const aldm_igemm_desc* d);
 /* Tuning override (tests / tools): force the block tile and split-K factor of subsequent
  * aldm_igemm calls on this thread; bm = 0 => automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
 void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
@@ -172,20 +178,25 @@ int aldm_igemm_mma(int mode);
  * aldm_split_bytes = size of that image.                                                                 */
 int64_t aldm_split_bytes(int K, int N);
 int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* stream);
+/* the same with `parts` = 2 | 3 parts per weight ([k-octet][parts][Npad][8 bf16]; 2 = (hi, mid) rounded to nearest,
+ * the "bf16x3" image of the DMA-fed kernel)                                                                     */
+int64_t aldm_split_bytes_parts(int K, int N, int parts);
+int aldm_pack_split_bf16_parts(const float* packed, void* dst, int K, int N, int parts, void* stream);
 
 /* ---- split images: pre-split activations for the DMA-fed GEMM (aldm_igemm_desc.a_split, ABI v5) -----------------
  * A split image of channels-last fp32 rows [rows, C] (C % 32 == 0) holds every value as its exact 3-way truncation
  * split x = hi + mid + lo (bf16 bit patterns), blocked [row][C/32][part][32]: 6 bytes per element, 192 contiguous
- * bytes per (row, 32-channel block).  Producers: aldm_split_rows (below), aldm_layernorm_split,
+ * bytes per (row, 32-channel block); with parts = 2 ("bf16x3") only (hi, mid), both rounded to nearest: 4 bytes per
+ * element, 128 bytes per block.  Producers: aldm_split_rows (below), aldm_layernorm_split,
  * aldm_attention_d32_split and aldm_igemm's out_split.                                                            */
-int64_t aldm_split_image_bytes(int64_t rows, int C);
+int64_t aldm_split_image_bytes(int64_t rows, int C, int parts);
 /* dst = split(act(x*scale[b, c] + shift[b, c])) with x = x1 ++ x2 along C ([rows, C1] / [rows, C2], P rows per
  * sample; scale/shift [rows/P, C1+C2] or NULL = no affine; act = ALDM_ACT_NONE | ALDM_ACT_SILU): GroupNorm apply +
  * SiLU (openaimodel.py:227-231,280-283; attention.py:459) and the skip concat (openaimodel.py:879) done ONCE per
  * element instead of once per conv tap inside the GEMM.  dst_raw (optional): split(x) of the same rows (the 1x1 skip
  * conv's operand, openaimodel.py:267).                                                                            */
 int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
-                    const float* shift, int act, void* dst, void* dst_raw, void* stream);
+                    const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1
@@ -215,7 +226,7 @@ int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                    const float* beta, float eps, void* stream);
 /* same, writing the result as a split image (y_split, C % 32 == 0) and optionally also as fp32 (y may be NULL)    */
 int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
-                         const float* beta, float eps, void* stream);
+                         const float* beta, float eps, int parts, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------ */
 /* Multi-head attention, head dim 32, flash-style online softmax on fp32 MFMA:
@@ -229,12 +240,23 @@ int aldm_attention_d32(const float* q, const float* k, const float* v, float* ou
 /* same, writing the result (also / only: out may be NULL) as a split image with heads*32 channels per row — the
  * pre-split A operand of the to_out projection (attention.py:366)                                               */
 int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
-                             int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+                             int parts, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                              const float* mask, float scale, void* stream);
 /* Matrix-core path of aldm_attention_d32 on this thread: 1 = fp32 MFMA, 2 = bf16-split (both products as 6 bf16 partial
- * products of exact operand splits, like the igemm engine), -1 = default ($ALDM_ATTN_MMA, "f32" unless it says
- * "bf16x6").  Returns the previous mode.                                                                        */
+ * products of exact operand splits, like the igemm engine), -1 = default (bf16-split unless $ALDM_ATTN_MMA says
+ * "f32").  Returns the previous mode.                                                                           */
 int aldm_attention_mma(int mode);
+/* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,
+ * window_size = `window` <= 8, shared heads): per head h (channels [h*d, (h+1)*d), d <= 128)
+ *   s[i, j] = (q_i/sqrt(d)).k_j + [|j-i| <= window] (q_i/sqrt(d)).emb_k[j-i+window];  s = -1e4 where mask_i*mask_j == 0;
+ *   out_i = softmax_j(s) v + sum_r p[i, i+r-window] emb_v[r].   q/k/v/out: [B, T, *] rows with pitches ld*; emb_*:
+ * [2*window+1, d]; mask [B, T] (1 = token).  Exact fp32 FMA (a once-per-prompt conditioner, latency bound).       */
+int aldm_rel_attention(const float* q, const float* k, const float* v, float* out, int B, int heads, int T, int d,
+                       int ldq, int ldk, int ldv, int ldo, const float* emb_k, const float* emb_v, int window,
+                       const float* mask, void* stream);
+/* y[r, c] = x[r, c] * s[r] (+ res[r, c] when res != NULL): the x * x_mask of the encoder's conv FFN
+ * (attentions.py:406-413) and the final + positional embedding (encoders/modules.py:103)                          */
+int aldm_rowscale_add(const float* x, const float* s, const float* res, float* y, int64_t rows, int C, void* stream);
 /* row softmax with pre-scale: y = softmax(scale * x) over the last dim of [M, N]
  * (model.py:220-221)                                                                        */
 int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale, void* stream);

@@ -143,3 +143,33 @@ def seqgen_cond(cfg: dict, B: int, T: int, seed: int = 5) -> dict:
     mask = torch.ones(B, T)
     mask[1::2, T - T // 4:] = 0
     return {cfg["keys"][0]: film, cfg["keys"][1]: [seq, mask]}
+
+
+# --- VITS phoneme encoder (second half; config 5) --------------------------------------------
+PHONEME = {"vocabs_size": 183, "pad_token_id": 0, "pad_length": 310}   # utils.py:156-165
+
+
+def phoneme_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """Deterministic weights for PhonemeEncoder; the relative-position tables and the positional embedding get O(0.1)
+    values (their fan-in-scaled defaults would be ~1e-3 and a wrong relative-position shift would go unnoticed)."""
+    import math
+    from . import weights
+    sd = weights.make_state_dict(shapes, seed=seed)
+    for k, v in sd.items():
+        if "emb_rel_" in k or k == "learnable_positional_embedding":
+            fan = 1
+            for s_ in v.shape[1:]:
+                fan *= s_
+            sd[k] = v * math.sqrt(fan) * 0.3
+    return sd
+
+
+def phoneme_input(seed: int = 7) -> torch.Tensor:
+    """[4, 310] token ids: a full-length row, two padded rows (57 and 6 tokens: shorter than the +-4 window too) and a
+    single-token row; pad id 0 at the end, as the reference's dataloader pads (commons.sequence_mask assumes it)."""
+    g = torch.Generator().manual_seed(seed)
+    T = PHONEME["pad_length"]
+    idx = torch.randint(1, PHONEME["vocabs_size"], (4, T), generator=g)
+    for b, n in enumerate((T, 57, 6, 1)):
+        idx[b, n:] = PHONEME["pad_token_id"]
+    return idx

@@ -286,6 +286,25 @@ def gen_seqgen():
             json.dump({k: list(v) for k, v in shapes.items()}, f)
 
 
+def gen_phoneme():
+    """§8(f) rank 1, second half: the REAL PhonemeEncoder (encoders/modules.py:30-110 over phoneme_encoder/encoder.py and
+    attentions.py) at the speech model's configuration, deterministic weights: a padded batch and the unconditional
+    (all-pad) condition."""
+    m = refimport.phoneme_encoder(**cases.PHONEME)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = cases.phoneme_state_dict(shapes)
+    m.load_state_dict(sd, strict=True)
+    idx = cases.phoneme_input()
+    t0 = time.time()
+    emb, mask = m(idx)
+    uemb, umask = m.get_unconditional_condition(2)
+    print(f"phoneme: reference PhonemeEncoder B={idx.shape[0]}: {time.time()-t0:.2f}s emb {tuple(emb.shape)} std {emb.std():.3f} "
+          f"mask sum {mask.sum(-1).tolist()}")
+    save("phoneme_speech_b4", emb=emb, mask=mask, uncond_emb=uemb, uncond_mask=umask)
+    with open(os.path.join(OUT, "phoneme_keys.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f)
+
+
 def _seed_all():
     import random
     random.seed(cases.E2E_SEED)
@@ -367,5 +386,7 @@ if __name__ == "__main__":
         gen_e2e_named("audioldm2-full-large-1150k", 2, 1, "e2e_large_2step_b1", "e2elarge_statedict_keys.json")
     if "all" in what or "seqgen" in what:
         gen_seqgen()
+    if "all" in what or "phoneme" in what:
+        gen_phoneme()
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")

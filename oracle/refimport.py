@@ -124,3 +124,20 @@ def sequence_generator(sequence_gen_length: int, sequence_input_key, sequence_in
                              sequence_input_key=list(sequence_input_key),
                              sequence_input_embed_dim=list(sequence_input_embed_dim), cond_stage_config={},
                              batchsize=16).eval()
+
+
+def phoneme_encoder(vocabs_size: int, pad_length: int, pad_token_id: int):
+    """The real `PhonemeEncoder` (audioldm2/latent_diffusion/modules/encoders/modules.py:30-110).  refimport pre-seeds a
+    stand-in for that module (it pulls Hub tokenizers at import), so the class is taken from the file itself, loaded
+    under a private name with the un-installable imports stubbed."""
+    install()
+    import importlib.util
+    import sys
+    path = os.path.join(REF_ROOT, "audioldm2", "latent_diffusion", "modules", "encoders", "modules.py")
+    name = "_aldm_ref_encoders_modules"
+    if name not in sys.modules:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules[name].PhonemeEncoder(vocabs_size=vocabs_size, pad_length=pad_length, pad_token_id=pad_token_id).eval()

@@ -43,7 +43,7 @@ def make_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, gain: float = 
         bound = gain / math.sqrt(fan_in)
         return (torch.rand(shape, generator=g) * 2 - 1) * bound
     # 1-D: norm gain, or bias
-    if leaf == "weight":
+    if leaf in ("weight", "gamma"):  # norm gains (VITS LayerNorm names them gamma / beta)
         return 1.0 + 0.1 * torch.randn(shape, generator=g)
     return 0.05 * torch.randn(shape, generator=g)
 

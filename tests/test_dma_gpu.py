@@ -30,12 +30,28 @@ def g(seed=0):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["bf16x6", "bf16x3"])
+def ops(request):
+    """Both split modes of the DMA-fed kernel: "bf16x6" (exact 3-part images, 6 partial products) and "bf16x3" ((hi, mid)
+    rounded to nearest, 3 partial products) — same GEMM tolerance: the 2^-18 unbiased operand rounding of bf16x3 averages
+    out over K and stays below the fp32 accumulation-order noise both share."""
     from audioldm2_amd import ops as o
-    prev = o.set_mma("bf16x6")
+    prev = o.set_mma(request.param)
     yield o
     o.set_mma(prev)
+
+
+def exact_split(ops):
+    return ops.split_parts() == 3
+
+
+def assert_split_equals(ops, s, ref, what=""):
+    """A 3-part image reproduces the fp32 values bitwise; a 2-part image to 2^-17 relative (round to nearest twice)."""
+    if exact_split(ops):
+        assert torch.equal(s.float(), ref), what
+    else:
+        err = (s.float().double() - ref.double()).abs()
+        assert bool((err <= ref.double().abs() * 2.0 ** -17 + 1e-38).all()), what
 
 
 def test_split_rows_is_exact_and_applies_groupnorm_silu(ops):
@@ -46,14 +62,14 @@ def test_split_rows_is_exact_and_applies_groupnorm_silu(ops):
     sh = torch.randn(B, C1 + C2, generator=g(4)).cuda()
     s, raw = ops.split_rows(x1, x2, pre=(sc, sh), act=ops.ACT_SILU, want_raw=True)
     xc = torch.cat([x1, x2], -1)
-    assert torch.equal(raw.float(), xc), "hi + mid + lo must reproduce x bitwise"
+    assert_split_equals(ops, raw, xc, "hi + mid (+ lo) must reproduce x")
     ref = F.silu(xc * sc[:, None, :] + sh[:, None, :])
-    assert rel_err(s.float(), ref) < 2e-6
+    assert rel_err(s.float(), ref) < (2e-6 if exact_split(ops) else 2e-5)   # 2-part image: 2^-16 per value
     s2 = ops.split_rows(x1, pre=(sc[:, :C1].contiguous(), sh[:, :C1].contiguous()))
     assert rel_err(s2.float(), x1.double() * sc[:, None, :C1].double() + sh[:, None, :C1].double()) < 2e-7  # one fma rounding
     # tiny / huge values keep the exact split too
     z = torch.tensor([1e-25, -3e38, 1.0000001, -0.0, 65504.0, 1e-30, 7.0, 3.14159] * 4).view(1, 1, 32).cuda()
-    assert torch.equal(ops.split_rows(z).float(), z)
+    assert_split_equals(ops, ops.split_rows(z), z)
 
 
 @pytest.mark.parametrize("B,C,N,H,W,k,s,p,up", [
@@ -78,12 +94,14 @@ def test_conv_on_split_operand(ops, B, C, N, H, W, k, s, p, up):
     assert rel_err(uncl(y), ref) < GEMM_TOL
 
 
-@pytest.mark.parametrize("bm,bn,st", [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2),
-                                      (64, 64, 3), (64, 64, 2)])
+@pytest.mark.parametrize("bm,bn,st", [(256, 128, 2), (256, 128, 3), (128, 128, 3), (128, 128, 4), (128, 128, 2), (64, 128, 4),
+                                      (64, 128, 2), (128, 64, 4), (128, 64, 2), (64, 64, 3), (64, 64, 2)])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_dma_every_tile_and_splitk(ops, bm, bn, st, splits):
     """Every instantiation, with and without split-K, ragged M, K = 38 k-tiles (ragged split), full epilogue, and the
     split-image second output equal to the fp32 one."""
+    if (bm, bn, st) in ([(256, 128, 3), (128, 128, 4)] if exact_split(ops) else [(128, 128, 3)]):
+        pytest.skip("ring depth not instantiated for this split mode")
     B, C, N, H, W = 3, 128, 96, 13, 7
     x = torch.randn(B, C, H, W, generator=g(1))
     w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
@@ -102,7 +120,8 @@ def test_dma_every_tile_and_splitk(ops, bm, bn, st, splits):
         ops.igemm_force(0, 0, 0)
     assert rel_err(uncl(y1), ref) < GEMM_TOL
     assert torch.equal(y1, y2), "must be bitwise reproducible"
-    assert torch.equal(s1.float(), y1) and torch.equal(s3.float(), y1)
+    assert_split_equals(ops, s1, y1)
+    assert_split_equals(ops, s3, y1)
 
 
 def test_dma_matches_register_staged_kernel_bitwise_class(ops):
@@ -113,7 +132,7 @@ def test_dma_matches_register_staged_kernel_bitwise_class(ops):
     pw = ops.pack_conv(w, None)
     y_old = ops.conv(cl(x), pw, pad=(1, 1))
     y_new = ops.conv(ops.split_rows(cl(x)), pw, pad=(1, 1))
-    assert rel_err(y_new, y_old) < 2e-6
+    assert rel_err(y_new, y_old) < (2e-6 if exact_split(ops) else 1e-5)
 
 
 def test_linear_geglu_layernorm_attention_split_chain(ops):
@@ -131,7 +150,8 @@ def test_linear_geglu_layernorm_attention_split_chain(ops):
     a, gate = h.chunk(2, -1)
     ff_ref = (a * F.gelu(gate)) @ w2.t() + b2 + x
     n_f, n_s = ops.layernorm(x.cuda(), ga.cuda(), be.cuda(), split_out="also")
-    assert rel_err(n_f, n_ref) < 2e-6 and torch.equal(n_s.float(), n_f)
+    assert rel_err(n_f, n_ref) < 2e-6
+    assert_split_equals(ops, n_s, n_f)
     gs = ops.linear_geglu(n_s, ops.pack_geglu(w1, b1), split_out="only")
     y = ops.linear(gs, ops.pack_conv(w2, b2), res=x.cuda())
     assert rel_err(y, ff_ref) < GEMM_TOL
@@ -141,9 +161,9 @@ def test_linear_geglu_layernorm_attention_split_chain(ops):
     k = torch.randn(2, Lk, heads * 32, generator=g(9))
     v = torch.randn(2, Lk, heads * 32, generator=g(10))
     o_f, o_s = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, split_out="also")
-    assert torch.equal(o_s.float(), o_f)
+    assert_split_equals(ops, o_s, o_f)
     o_only = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, split_out="only")
-    assert torch.equal(o_only.float(), o_f)
+    assert_split_equals(ops, o_only, o_f)
     qh = q.view(2, Lq, heads, 32).transpose(1, 2)
     kh = k.view(2, Lk, heads, 32).transpose(1, 2)
     vh = v.view(2, Lk, heads, 32).transpose(1, 2)

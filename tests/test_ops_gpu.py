@@ -280,6 +280,27 @@ def test_weight_split_image_is_bit_exact_vs_numpy_restatement(ops):
     assert img.size == ref.size and np.array_equal(img.reshape(ref.shape), ref)
 
 
+def test_two_part_weight_split_image_is_bit_exact_vs_numpy_restatement():
+    """aldm_pack_split_bf16_parts(parts = 2) — the "bf16x3" weight image of the DMA-fed kernel — against oracle/bf16x6.py,
+    bit for bit: (hi, mid) rounded to nearest even, layout [k-octet][2][Npad][8]."""
+    import numpy as np
+    from audioldm2_amd import ops as o
+    from oracle import bf16x6 as bx
+    N, Cin, KH, KW = 40, 12, 2, 3  # K = 72
+    w = torch.randn(N, Cin, KH, KW, generator=g(11)) * 0.05
+    prev = o.set_mma("bf16x3")
+    try:
+        pw = o.pack_conv(w)
+        assert pw.split_ptr(2) is not None
+        img = pw.split2.cpu().numpy().view(np.uint16)
+    finally:
+        o.set_mma(prev)
+    K = Cin * KH * KW
+    packed = bx.pack_kn(w.permute(2, 3, 1, 0).reshape(K, N).numpy())
+    ref = bx.split_image(packed, K, parts=2)
+    assert img.size == ref.size and np.array_equal(img.reshape(ref.shape), ref)
+
+
 def test_conv_upsample_nearest(ops):
     B, C, H, W = 2, 64, 8, 4
     x = torch.randn(B, C, H, W, generator=g(1))

@@ -18,16 +18,29 @@ sys.argv = sys.argv_saved
 from audioldm2_amd import lib as L  # noqa: E402
 from audioldm2_amd import ops  # noqa: E402
 
-CFGS = [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2), (64, 64, 3),
-        (64, 64, 2)]
+CFGS = {3: [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2), (64, 64, 3),
+            (64, 64, 2)],
+        2: [(256, 128, 3), (256, 128, 2), (128, 128, 4), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2),
+            (64, 64, 3), (64, 64, 2)]}
 SPLITS = [1, 2, 3, 4, 6, 8]
+PARTS = 2 if os.environ.get("ALDM_MMA") == "bf16x3" else 3
+SUFFIX = ",dma2" if PARTS == 2 else ",dma"
 
 
 def tune(key, lib):
-    d, keep, M, N, K = at.make_desc(key[:-len(",dma")])
+    d, keep, M, N, K = at.make_desc(key[:-len(SUFFIX)])
     npix = d.B * d.H * d.W
-    img = torch.randint(-2 ** 15, 2 ** 15, (npix * (d.C1 // 32) * 96,), device="cuda", dtype=torch.int16)
+    # operands = split images of random fp32 data (random bit patterns would change the chip's power draw, i.e. its clock)
+    x = torch.randn(npix, d.C1, device="cuda")
+    img = ops.split_rows(x)
+    assert img.parts == PARTS
     d.a_split = img.data_ptr()
+    d.split_parts = PARTS
+    if PARTS == 2:
+        w2 = torch.empty(lib.aldm_split_bytes_parts(K, N, 2) // 4, device="cuda", dtype=torch.int32)
+        keep.append(w2)
+        L.check(lib.aldm_pack_split_bf16_parts(d.w, w2.data_ptr(), K, N, 2, torch.cuda.current_stream().cuda_stream), "split2")
+        d.w_split = w2.data_ptr()
     d.x1 = None
     d.pre_scale = d.pre_shift = None
     d.pre_act = 0
@@ -38,7 +51,7 @@ def tune(key, lib):
     t_auto = at.time_launch(lib, d, reps)
     best = (t_auto, 0, 0, 0, 0)
     geglu = d.epi_mode == L.EPI_GEGLU
-    for bm, bn, st in CFGS:
+    for bm, bn, st in CFGS[PARTS]:
         if geglu and bn != 128:
             continue
         if bn > 64 and N <= 64 and not geglu:
@@ -61,16 +74,16 @@ def tune(key, lib):
 def main():
     out = sys.argv[1]
     models = sys.argv[2:] or ["audioldm2-full"]
-    ops.set_mma("bf16x6")
+    ops.set_mma("bf16x3" if PARTS == 2 else "bf16x6")
     ops.set_dma(True)
     lib = L.load()
     counts = {}
     for m in models:
         c = at.collect(m, 8)
         for k, n in c.items():
-            if k.endswith(",dma"):
+            if k.endswith(SUFFIX):
                 counts[k] = max(counts.get(k, 0), n)
-        print(f"# {m}: {sum(1 for k in c if k.endswith(',dma'))} unique DMA-fed igemm geometries", flush=True)
+        print(f"# {m}: {sum(1 for k in c if k.endswith(SUFFIX))} unique DMA-fed igemm geometries ({PARTS} parts)", flush=True)
     entries, total, saved = {}, 0.0, 0.0
     for key, n in sorted(counts.items()):
         t_auto, best, flops, mnk = tune(key, lib)
@@ -81,7 +94,7 @@ def main():
         print(f"M{mnk[0]} N{mnk[1]} K{mnk[2]} n={n} auto {t_auto:.1f}us -> best {best[1]}x{best[2]} k{best[3]} st{best[4]} "
               f"{best[0]:.1f}us {flops / best[0] / 1e6:.1f} TF", flush=True)
     with open(out, "w") as f:
-        json.dump({"device": "MI355X", "kernel": "igemm_dma_kernel", "entries": entries}, f, indent=0, sort_keys=True)
+        json.dump({"device": "MI355X", "kernel": "igemm_dma_kernel", "parts": PARTS, "entries": entries}, f, indent=0, sort_keys=True)
     print(f"# {len(entries)} tuned entries, {saved / 1e3:.2f} ms of {total / 1e3:.2f} ms (2-step job) saved", flush=True)
 
 

@@ -1,5 +1,5 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs as MI355X_MICROARCH.md
-prescribes) of the bench command into profiles/r01_pmc_traffic.json: average HBM bytes per launch for
+prescribes) of the bench command into profiles/rNN_pmc_traffic.json (stamped with audioldm2_amd.lib.source_hash()): average HBM bytes per launch for
 each igemm instantiation (tile x prologue mode, named as rocprofv3 names them).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of
 the bytes of wide (16 B/lane) coalesced reads (same guide) -> doubled here, raw value kept too.
 Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
@@ -19,7 +19,7 @@ def collect(root, counter):
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != counter:
                     continue
-                m = re.search(r"igemm_kernel<[^>]*>", r["Kernel_Name"])
+                m = re.search(r"igemm(?:_dma)?_kernel<[^>]*>", r["Kernel_Name"])
                 if not m:
                     continue
                 a = acc[m.group(0)]
@@ -31,7 +31,10 @@ def collect(root, counter):
 def main():
     fetch = collect(sys.argv[1], "FETCH_SIZE")
     write = collect(sys.argv[2], "WRITE_SIZE")
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) of "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from audioldm2_amd.lib import source_hash
+    out = {"source_hash": source_hash(),
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) of "
                      "ALDM_NO_GRAPH=1 python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline",
            "units": "bytes per launch, averaged over all launches of the instantiation (all prologue modes)",
            "kernels": {}}
