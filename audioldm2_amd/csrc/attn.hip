@@ -41,12 +41,32 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&part)[3]) {
     }
 }
 
+// (hi, mid) rounded to nearest — the "bf16x3" operands (igemm_epilogue.h split4_rn2): plain __bf16 conversions, which hipcc
+// lowers to v_cvt_pk_bf16_f32 (two values per instruction, already packed): 3 VALU per element instead of the truncation
+// split's 5.5, and two parts instead of three.
+__device__ __forceinline__ void split8_rn2(const float (&x)[8], bf16x8 (&part)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        part[0][j] = h;
+        part[1][j] = (__bf16)(x[j] - (float)h);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void split8_np(const float (&x)[8], bf16x8 (&part)[3]) {
+    if constexpr (NP == 2) split8_rn2(x, part);
+    else split8(x, part);
+}
+
 // QT = 32-query tiles per wave.  With QT = 2 one wave reuses every K / V fragment it loads for 64
 // queries (half the L1/L2 traffic per MFMA); used when the grid still fills the chip.
 // BX: both products on the bf16 matrix cores as 6 partial products of exact operand splits (Q once, K / V / P per
 // key tile, all in registers): 24 MFMAs of 32 cycles per 32x32 tile pair instead of 32 of 64.  The operand layouts
 // carry over unchanged: a 16-wide MFMA k-step takes 8 consecutive entries of what the fp32 kernel feeds one at a time.
-template <bool HAS_MASK, int QT, bool BX = false>
+// NP (BX only): 3 = "bf16x6" (exact 3-part splits, 6 partial products), 2 = "bf16x3" ((hi, mid) rounded to nearest, 3 partial
+// products: half the MFMAs and a cheaper split — the kernel is VALU bound on the splits and the exponentials).
+template <bool HAS_MASK, int QT, bool BX = false, int NP = 3>
 __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
                 float x8[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x8[j] = qf[t][8 * s + j];
-                split8(x8, qx[t][s]);
+                split8_np<NP>(x8, qx[t][s]);
             }
     }
 
@@ -128,7 +148,10 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         for (int t = 0; t < QT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
-        constexpr int PA_[6] = {0, 2, 1, 0, 1, 0}, PB_[6] = {2, 0, 1, 1, 0, 0};  // (lo-order products first)
+        // (lo-order products first; NP = 2: mid*hi, hi*mid, hi*hi)
+        constexpr int NPROD = NP == 3 ? 6 : 3;
+        constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
+        constexpr int PB_[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
         if constexpr (BX) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -136,9 +159,9 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
                 bf16x8 kx[3];
-                split8(x8, kx);
+                split8_np<NP>(x8, kx);
 #pragma unroll
-                for (int p = 0; p < 6; ++p)
+                for (int p = 0; p < NPROD; ++p)
 #pragma unroll
                     for (int t = 0; t < QT; ++t)
                         st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx[PA_[p]], qx[t][s][PB_[p]], st[t], 0, 0, 0);
@@ -189,15 +212,15 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
                 bf16x8 vx[3];
-                split8(x8, vx);
+                split8_np<NP>(x8, vx);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x8[j] = st[t][8 * s + j];
                     bf16x8 px[3];
-                    split8(x8, px);
+                    split8_np<NP>(x8, px);
 #pragma unroll
-                    for (int p = 0; p < 6; ++p)
+                    for (int p = 0; p < NPROD; ++p)
                         oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vx[PA_[p]], px[PB_[p]], oT[t], 0, 0, 0);
                 }
             }
@@ -234,20 +257,22 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
 
 using namespace aldm;
 
-// matrix-core path of the attention kernel: -1 = default (bf16-split since round 2: 1024x1024 self-attention 202 -> 139 us
-// on MI355X, agreement with the fp32-MFMA kernel 1.6e-6, profiles/r02_attn_ab.txt; $ALDM_ATTN_MMA=f32 switches back),
-// 1 = fp32 MFMA, 2 = bf16-split
+// matrix-core path of the attention kernel: -1 = default (bf16x3 since round 2: 1024x1024 self-attention 202 us on the
+// fp32 MFMA, 139 us as bf16x6, see profiles/r02_attn_ab*.txt; $ALDM_ATTN_MMA = f32 | bf16x6 | bf16x3 overrides),
+// 1 = fp32 MFMA, 2 = bf16x6, 3 = bf16x3
 static thread_local int g_attn_mma = -1;
-static bool default_attn_bx() {
-    static const bool v = [] {
+static int default_attn_mode() {
+    static const int v = [] {
         const char* e = getenv("ALDM_ATTN_MMA");
-        return !(e != nullptr && e[0] == 'f');
+        if (e == nullptr) return 3;
+        if (e[0] == 'f') return 1;
+        return (e[0] == 'b' && e[4] == 'x' && e[5] == '6') ? 2 : 3;
     }();
     return v;
 }
 extern "C" int aldm_attention_mma(int mode) {
     const int prev = g_attn_mma;
-    if (mode == -1 || mode == 1 || mode == 2) g_attn_mma = mode;
+    if (mode == -1 || (mode >= 1 && mode <= 3)) g_attn_mma = mode;
     return prev;
 }
 
@@ -275,15 +300,16 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
         return e ? atoi(e) : 0;
     }();
     const bool qt2 = env_qt ? env_qt == 2 : (Lk >= 256 && (int64_t)cdiv(Lq, 256) * heads * B >= 512);
-    const bool bx = g_attn_mma < 0 ? default_attn_bx() : g_attn_mma == 2;
+    const int amode = g_attn_mma < 0 ? default_attn_mode() : g_attn_mma;
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
-#define ALDM_ATTN(M_, Q_, X_)                                                                                 \
-    hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
+#define ALDM_ATTN(M_, Q_, X_, P_)                                                                                 \
+    hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_, P_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
                        ldk, ldv, ldo, mask, scale, out_split, split_c, parts)
-#define ALDM_ATTN_X(M_, Q_)          \
-    do {                             \
-        if (bx) ALDM_ATTN(M_, Q_, true); \
-        else ALDM_ATTN(M_, Q_, false);   \
+#define ALDM_ATTN_X(M_, Q_)                         \
+    do {                                            \
+        if (amode == 3) ALDM_ATTN(M_, Q_, true, 2);  \
+        else if (amode == 2) ALDM_ATTN(M_, Q_, true, 3); \
+        else ALDM_ATTN(M_, Q_, false, 3);            \
     } while (0)
     if (mask) {
         if (qt2) ALDM_ATTN_X(true, 2);

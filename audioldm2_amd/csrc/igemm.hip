@@ -267,7 +267,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.epi_mode == ALDM_EPI_PLAIN || geglu, "aldm_igemm: unknown epi_mode %d", d.epi_mode);
     if (geglu) {
         ALDM_CHECK(d.N % 64 == 0 && d.ldo >= d.N / 2 && d.ldo % 4 == 0 && d.b_mode == ALDM_B_PACKED &&
-                       d.out_mul == 0 && !d.res && !d.rowbias && !d.accumulate && d.act == ALDM_ACT_NONE &&
+                       d.out_mul == 0 && !d.res && !d.rowbias && !d.accumulate &&
+                       (d.act == ALDM_ACT_NONE || d.act == ALDM_ACT_GELU_TANH) &&
                        (reinterpret_cast<uintptr_t>(d.out) & 15) == 0 && d.stride_o % 4 == 0 &&
                        (d.bias == nullptr || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0),
                    "aldm_igemm: GEGLU epilogue needs N %% 64 == 0, ldo >= N/2, packed weights, a plain epilogue");

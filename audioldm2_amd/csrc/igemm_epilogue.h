@@ -156,6 +156,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                 bg = *reinterpret_cast<const f32x4*>(d.bias + ncol_p + 32);
             }
             float* go = d.out ? d.out + (int64_t)z * d.stride_o : nullptr;
+            // gate activation: erf GELU (attention.py:44) unless the descriptor asks for the tanh form (T5 gated-gelu FF)
+            const int gate_act = d.act == ALDM_ACT_GELU_TANH ? ALDM_ACT_GELU_TANH : ALDM_ACT_GELU;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -169,7 +171,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                     f32x4 xv = *reinterpret_cast<const f32x4*>(&stg[r * SP + gc]) + bv;
                     const f32x4 xg = *reinterpret_cast<const f32x4*>(&stg[r * SP + 32 + gc]) + bg;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[c] *= act_apply(xg[c], ALDM_ACT_GELU, 0.f);
+                    for (int c = 0; c < 4; ++c) xv[c] *= act_apply(xg[c], gate_act, 0.f);
                     const int m = m0 + (wm * MT + i) * 32 + r;
                     if (m < p.M && cok) {
                         if (go) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;

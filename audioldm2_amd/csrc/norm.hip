@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // flight per wave hide that latency.
 constexpr int LN_MAXV = 8;
 
-template <int MAXV, int R>
+// RMS = true: T5LayerNorm (transformers T5: y = w * x * rsqrt(mean(x^2) + eps), no mean subtraction, no bias).
+template <int MAXV, int R, bool RMS = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         float* __restrict__ y, int M, int C,
                                                         const float* __restrict__ gamma,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < MAXV; ++i) {
         const int c4 = min(lane + 64 * i, C4 - 1);
         ga[i] = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
-        be[i] = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+        be[i] = RMS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(beta + 4 * c4);
     }
     float mean[R], rstd[R];
 #pragma unroll
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         for (int i = 0; i < MAXV; ++i) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        mean[r] = s / (float)C;
+        mean[r] = RMS ? 0.f : s / (float)C;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -280,11 +281,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // iff keymask[b, j] != 0 and j <= q_pos0 + i (causal); excluded keys get weight exactly 0 (the reference adds finfo.min
 // to them, transformers GPT2Attention: same result whenever a row keeps at least one key, which the always-unmasked
 // start token guarantees).
-template <bool MASKED>
+// BIASED (T5 self-attention, transformers T5Attention): row r = (b * heads + h) * q_rows + i gets bias[h, i, :] added and
+// keys with keymask[b, j] == 0 the additive finfo.min of the reference's extended attention mask (weight exactly 0 while
+// the row keeps a key); no causal limit.
+template <bool MASKED, bool BIASED = false>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
                                                            float* __restrict__ y, int N,
                                                            float scale, const float* __restrict__ keymask,
-                                                           int rows_per_batch, int q_rows, int q_pos0) {
+                                                           int rows_per_batch, int q_rows, int q_pos0,
+                                                           const float* __restrict__ bias = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float srow[];
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
@@ -294,12 +299,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float mx = -INFINITY;
     const float* km = nullptr;
     int jmax = N;
+    const float* br = nullptr;
     if (MASKED) {
         km = keymask + (row / rows_per_batch) * N;
-        jmax = q_pos0 + (int)(row % q_rows) + 1;  // keys [0, jmax) are causally visible
+        jmax = BIASED ? N : q_pos0 + (int)(row % q_rows) + 1;  // keys [0, jmax) are causally visible
     }
+    if (BIASED) br = bias + (row % rows_per_batch) * N;          // [heads, q_rows, N] shared by the batch
     for (int i = tid; i < N; i += 256) {
         float v = xr[i] * scale;
+        if (BIASED) v += br[i];
         if (MASKED && (i >= jmax || km[i] == 0.0f)) v = -INFINITY;
         srow[i] = v;
         mx = fmaxf(mx, v);
@@ -370,16 +378,22 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
 }
 
 static int layernorm_launch(const float* x, float* y, void* y_split, int parts, int M, int C, const float* gamma,
-                            const float* beta, float eps, void* stream, const char* name) {
+                            const float* beta, float eps, void* stream, const char* name, bool rms = false) {
     ALDM_CHECK(parts == 2 || parts == 3, "%s: parts must be 2 or 3", name);
-    ALDM_CHECK(x && (y || y_split) && gamma && beta, "%s: null pointer", name);
+    ALDM_CHECK(x && (y || y_split) && gamma && (beta || rms), "%s: null pointer", name);
     ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "%s: C=%d must be a multiple of 4 and <= %d", name, C, 256 * LN_MAXV);
     ALDM_CHECK(y_split == nullptr || (C % 32 == 0 && (reinterpret_cast<uintptr_t>(y_split) & 15) == 0),
                "%s: a split-image output needs C %% 32 == 0 and 16-byte alignment", name);
     hipStream_t st = (hipStream_t)stream;
-#define ALDM_LN(V_, R_)                                                                                  \
-    hipLaunchKernelGGL((layernorm_kernel<V_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, C, \
-                       gamma, beta, eps, y_split, parts)
+#define ALDM_LN(V_, R_)                                                                                             \
+    do {                                                                                                            \
+        if (rms)                                                                                                    \
+            hipLaunchKernelGGL((layernorm_kernel<V_, R_, true>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, C, \
+                               gamma, beta, eps, y_split, parts);                                                   \
+        else                                                                                                        \
+            hipLaunchKernelGGL((layernorm_kernel<V_, R_, false>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, \
+                               C, gamma, beta, eps, y_split, parts);                                                \
+    } while (0)
     const int nv = cdiv(C / 4, 64);
     if (nv <= 1) ALDM_LN(1, 4);
     else if (nv <= 2) ALDM_LN(2, 4);
@@ -398,6 +412,10 @@ extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const floa
 extern "C" int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
                                     const float* beta, float eps, int parts, void* stream) {
     return layernorm_launch(x, y, y_split, parts, M, C, gamma, beta, eps, stream, "aldm_layernorm_split");
+}
+
+extern "C" int aldm_rmsnorm(const float* x, float* y, int M, int C, const float* weight, float eps, void* stream) {
+    return layernorm_launch(x, y, nullptr, 3, M, C, weight, nullptr, eps, stream, "aldm_rmsnorm", true);
 }
 
 extern "C" int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale,
@@ -421,5 +439,17 @@ extern "C" int aldm_softmax_rows_masked(const float* x, float* y, int B, int hea
     hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3((unsigned)M), dim3(256), (size_t)N * 4, (hipStream_t)stream, x, y,
                        N, scale, keymask, heads * q_rows, q_rows, q_pos0);
     ALDM_LAUNCH_CHECK("aldm_softmax_rows_masked");
+    return 0;
+}
+
+extern "C" int aldm_softmax_rows_bias(const float* x, float* y, int B, int heads, int q_rows, int N, float scale,
+                                      const float* bias, const float* keymask, void* stream) {
+    ALDM_CHECK(x && y && bias && keymask && B > 0 && heads > 0 && q_rows > 0 && N > 0, "aldm_softmax_rows_bias: bad args");
+    ALDM_CHECK((int64_t)N * 4 <= 60 * 1024, "aldm_softmax_rows_bias: row of %d floats exceeds the 60 KiB LDS stage", N);
+    const int64_t M = (int64_t)B * heads * q_rows;
+    ALDM_CHECK(M < (1ll << 31), "aldm_softmax_rows_bias: too many rows");
+    hipLaunchKernelGGL((softmax_rows_kernel<true, true>), dim3((unsigned)M), dim3(256), (size_t)N * 4, (hipStream_t)stream, x,
+                       y, N, scale, keymask, heads * q_rows, q_rows, 0, bias);
+    ALDM_LAUNCH_CHECK("aldm_softmax_rows_bias");
     return 0;
 }

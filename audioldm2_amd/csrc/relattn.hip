@@ -143,12 +143,16 @@ __global__ __launch_bounds__(256) void rel_attention_kernel(const float* __restr
 }
 
 // y[r, c] = x[r, c] * s[r] (+ res[r, c])   (x * x_mask around the FFN convs, attentions.py:406-413; + positional embedding)
+// divide != 0: y = x / max(s[r], 1e-12) — F.normalize with s = the row norms (CLAP embeddings, clap/open_clip/model.py:745)
 __global__ void rowscale_add_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                    const float* __restrict__ res, float* __restrict__ y, int64_t rows, int C4) {
+                                    const float* __restrict__ res, float* __restrict__ y, int64_t rows, int C4,
+                                    int divide) {
     const int64_t total = rows * C4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / C4;
-        f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * s[r];
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        if (divide) v = v / fmaxf(s[r], 1e-12f);
+        else v = v * s[r];
         if (res) v += reinterpret_cast<const f32x4*>(res)[i];
         reinterpret_cast<f32x4*>(y)[i] = v;
     }
@@ -180,13 +184,13 @@ extern "C" int aldm_rel_attention(const float* q, const float* k, const float* v
 }
 
 extern "C" int aldm_rowscale_add(const float* x, const float* s, const float* res, float* y, int64_t rows, int C,
-                                 void* stream) {
+                                 int divide, void* stream) {
     ALDM_CHECK(x && s && y && rows > 0 && C > 0 && C % 4 == 0, "aldm_rowscale_add: bad args");
     ALDM_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0,
                "aldm_rowscale_add: operands must be 16-byte aligned");
     const int64_t total = rows * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(rowscale_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, s, res, y, rows, C / 4);
+    hipLaunchKernelGGL(rowscale_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, s, res, y, rows, C / 4, divide);
     ALDM_LAUNCH_CHECK("aldm_rowscale_add");
     return 0;
 }

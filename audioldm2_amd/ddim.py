@@ -108,6 +108,14 @@ class _NoiseFeed:
         self.events = {}
         self.produced = 0  # chunks drawn so far
 
+    def _draw_into(self, dst):
+        """One reference-ordered draw into a (pinned) staging row."""
+        d = self.draw
+        if getattr(d, "into", None) is not None:
+            d.into(dst)
+        else:
+            dst.numpy()[...] = d().numpy()   # plain memcpy, no thread pool
+
     def produce_next(self):
         c = self.produced
         if c + 1 >= len(self.bounds):
@@ -117,13 +125,18 @@ class _NoiseFeed:
         prev = self.events.get(c - len(self.pin))
         if prev is not None:
             prev.synchronize()  # the upload that last used this pinned slot is done
+        # Host side of the RNG contract.  The draws go STRAIGHT into the pinned staging rows (`torch.randn(out=...)`: same
+        # generator stream, no intermediate tensor): a 1 MB `Tensor.copy_` through torch's intra-op thread pool costs
+        # ~20 ms on a many-core host (measured: 19 ms with 8 threads on 8 busy vCPUs vs 0.02 ms with 4) — 200 of them
+        # per job had become the bound of the whole job (5.3 s) once the UNet step dropped under 25 ms.
         for s in range(lo, hi):  # reference order per step
             if self.with_mask and self.mask_first:
-                self.qpin[slot][s - lo].copy_(self.draw())
-            n = self.draw()
-            self.pin[slot][s - lo].copy_(n * self.temperature if self.temperature != 1.0 else n)
+                self._draw_into(self.qpin[slot][s - lo])
+            self._draw_into(self.pin[slot][s - lo])
+            if self.temperature != 1.0:
+                self.pin[slot][s - lo].mul_(self.temperature)
             if self.with_mask and not self.mask_first:
-                self.qpin[slot][s - lo].copy_(self.draw())
+                self._draw_into(self.qpin[slot][s - lo])
         with torch.cuda.stream(self.stream):
             self.noise[lo:hi].copy_(self.pin[slot][:hi - lo], non_blocking=True)
             if self.with_mask:
@@ -143,6 +156,30 @@ class _NoiseFeed:
         if first:
             torch.cuda.current_stream().wait_event(self.events[c])
         return first
+
+
+def host_drawer(shape, noise_shard=None):
+    """draw() -> one `torch.randn(shape)` from the host default generator, in the reference's order; draw.into(dst) writes
+    it into `dst`.  noise_shard = (global_batch, row_offset): a prompt-sharded run draws the GLOBAL batch like the
+    single-process reference and keeps rows [offset, offset + shape[0]) (dist.py)."""
+    shape = tuple(shape)
+    if noise_shard is None:
+        def draw():
+            return torch.randn(shape)
+
+        def into(dst):
+            torch.randn(shape, out=dst)
+    else:
+        gB, off = noise_shard
+        gshape = (gB,) + shape[1:]
+
+        def draw():
+            return torch.randn(gshape)[off:off + shape[0]].contiguous()
+
+        def into(dst):
+            dst.numpy()[...] = torch.randn(gshape)[off:off + shape[0]].numpy()
+    draw.into = into
+    return draw
 
 
 class DDIMSampler(object):
@@ -204,13 +241,9 @@ class DDIMSampler(object):
 
     # ------------------------------------------------------------------------------------------
     def _drawer(self, shape):
-        """One reference-ordered Gaussian draw from the HOST default generator (RNG contract R)."""
-        if self.noise_shard is None:
-            return lambda: torch.randn(shape)
-        # prompt-sharded run: draw the GLOBAL batch like the single-process reference, keep our rows
-        gB, off = self.noise_shard
-        gshape = (gB,) + tuple(shape[1:])
-        return lambda: torch.randn(gshape)[off:off + shape[0]].contiguous()
+        """One reference-ordered Gaussian draw from the HOST default generator (RNG contract R).  The returned callable
+        also has `.into(dst)`: the same draw written into an existing host tensor."""
+        return host_drawer(shape, self.noise_shard)
 
     def _draw_noise(self, shape, steps, x_T, with_mask):
         """Replays the reference's host RNG order: x_T, then per step [q_sample noise (inpainting

@@ -54,6 +54,12 @@ def set_mma(mode: str) -> str:
     global MMA_MODE
     assert mode in ("f32", "bf16x6", "bf16x3"), mode
     prev, MMA_MODE = MMA_MODE, mode
+    if _l._lib is not None or os.path.exists(_l.LIB_PATH):
+        try:  # the attention kernel follows the engine's mode unless $ALDM_ATTN_MMA pins it
+            if "ALDM_ATTN_MMA" not in os.environ:
+                _l.load().aldm_attention_mma({"f32": 1, "bf16x6": 2, "bf16x3": 3}[mode])
+        except RuntimeError:
+            pass
     return prev
 
 
@@ -396,7 +402,7 @@ def pack_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Packed:
     return pack_conv(weight.detach()[perm], None if bias is None else bias.detach()[perm])
 
 
-def linear_geglu(x, pw: Packed, split_out: Optional[str] = None):
+def linear_geglu(x, pw: Packed, split_out: Optional[str] = None, gate_act: int = ACT_NONE):
     """y = value * gelu_erf(gate) with [value | gate] = x @ W^T + b fused into the GEMM epilogue
     (attention.py:37-45); pw from pack_geglu.  x: [..., Cin] fp32 or SplitT -> [..., N/2] (split_out: None -> fp32,
     "only" -> SplitT, "also" -> (fp32, SplitT))."""
@@ -426,6 +432,7 @@ def linear_geglu(x, pw: Packed, split_out: Optional[str] = None):
     if so is not None:
         d.out_split = so.data_ptr(); d.out_split_c = pw.N // 2
     d.epi_mode = _l.EPI_GEGLU; d.batch = 1
+    d.act = gate_act  # ACT_GELU_TANH: tanh-GELU gate (T5 gated-gelu FF); default erf GELU (attention.py:44)
     _igemm(d, "igemm(geglu)")
     return so if split_out == "only" else ((out, so) if split_out else out)
 
@@ -680,6 +687,28 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *,
     return so if split_out == "only" else (out, so)
 
 
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """T5LayerNorm over the last dim: weight * x * rsqrt(mean(x^2) + eps)."""
+    _chk(x, "rmsnorm.x")
+    Cc = x.shape[-1]
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_rmsnorm(x.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc, weight.data_ptr(), eps, _stream()),
+             "rmsnorm")
+    return y
+
+
+def softmax_rows_bias(x: torch.Tensor, bias: torch.Tensor, keymask: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """x: [B, heads, q_rows, N] scores; bias [heads, q_rows, N] added to every batch entry; keymask [B, N] (0 = padded key,
+    weight 0)."""
+    _chk(x, "softmax_bias.x"); _chk(bias, "softmax_bias.bias"); _chk(keymask, "softmax_bias.keymask")
+    B, heads, q_rows, N = x.shape
+    assert bias.shape == (heads, q_rows, N) and keymask.shape == (B, N)
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_softmax_rows_bias(x.data_ptr(), y.data_ptr(), B, heads, q_rows, N, scale, bias.data_ptr(),
+                                              keymask.data_ptr(), _stream()), "softmax_rows_bias")
+    return y
+
+
 def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, emb_k: torch.Tensor, emb_v: torch.Tensor,
                   mask: torch.Tensor) -> torch.Tensor:
     """Windowed relative-position self-attention (VITS phoneme encoder, attentions.py:239-289).  q/k/v: [B, T, heads*d]
@@ -699,8 +728,8 @@ def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     return out
 
 
-def rowscale_add(x: torch.Tensor, s: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y[r, c] = x[r, c] * s[r] (+ res[r, c]); x: [..., C], s: one scale per row."""
+def rowscale_add(x: torch.Tensor, s: torch.Tensor, res: Optional[torch.Tensor] = None, divide: bool = False) -> torch.Tensor:
+    """y[r, c] = x[r, c] * s[r] (+ res[r, c]); x: [..., C], s: one scale per row.  divide: y = x / max(s[r], 1e-12)."""
     _chk(x, "rowscale.x"); _chk(s, "rowscale.s")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
@@ -709,8 +738,8 @@ def rowscale_add(x: torch.Tensor, s: torch.Tensor, res: Optional[torch.Tensor] =
         _chk(res, "rowscale.res")
         assert res.shape == x.shape
     y = torch.empty_like(x)
-    _l.check(_l.load().aldm_rowscale_add(x.data_ptr(), s.data_ptr(), _p(res), y.data_ptr(), rows, Cc, _stream()),
-             "rowscale_add")
+    _l.check(_l.load().aldm_rowscale_add(x.data_ptr(), s.data_ptr(), _p(res), y.data_ptr(), rows, Cc, 1 if divide else 0,
+                                         _stream()), "rowscale_add")
     return y
 
 

@@ -421,12 +421,8 @@ class LatentDiffusion(nn.Module):
             timesteps = self.num_timesteps
         if start_T is not None:
             timesteps = min(timesteps, start_T)
-        if getattr(self, "noise_shard", None) is None:
-            draw = lambda: torch.randn(shape)
-        else:  # prompt-sharded run: draw the GLOBAL batch like the single-process reference, keep our rows
-            gB, off = self.noise_shard
-            gshape = (gB,) + tuple(shape[1:])
-            draw = lambda: torch.randn(gshape)[off:off + shape[0]].contiguous()
+        from .ddim import host_drawer
+        draw = host_drawer(shape, getattr(self, "noise_shard", None))   # sharded runs draw the global batch, keep our rows
         img_h = draw() if x_T is None else x_T.detach().float().cpu()
         x_cur = img_h.to(dev).contiguous()
         # coefficient rows indexed by t, visited t = timesteps-1 .. 0; no noise at t == 0

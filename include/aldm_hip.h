@@ -46,7 +46,8 @@ enum {
  * stored: out[m, g*32 + l] = (acc[m, g*64 + l] + bias) * gelu_erf(acc[m, g*64 + 32 + l] + bias),
  * i.e. the weight's output channels are interleaved in groups of 32 (value block, gate block)
  * — pack with aldm_pack_weight from a weight whose rows were permuted that way.  N (the packed
- * width, 2*C) must be a multiple of 64, ldo >= N/2, no split-K, activation/rowbias unused.   */
+ * width, 2*C) must be a multiple of 64, ldo >= N/2, no split-K, rowbias unused; act = ALDM_ACT_GELU_TANH selects the tanh
+ * GELU for the gate (the gated-GELU FF of the FLAN-T5 conditioner: wo(gelu_new(wi_0 x) * wi_1 x)), otherwise erf GELU. */
 enum { ALDM_EPI_PLAIN = 0, ALDM_EPI_GEGLU = 1 };
 
 /* B-operand layouts of aldm_igemm */
@@ -242,9 +243,9 @@ int aldm_attention_d32(const float* q, const float* k, const float* v, float* ou
 int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
                              int parts, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                              const float* mask, float scale, void* stream);
-/* Matrix-core path of aldm_attention_d32 on this thread: 1 = fp32 MFMA, 2 = bf16-split (both products as 6 bf16 partial
- * products of exact operand splits, like the igemm engine), -1 = default (bf16-split unless $ALDM_ATTN_MMA says
- * "f32").  Returns the previous mode.                                                                           */
+/* Matrix-core path of aldm_attention_d32 on this thread: 1 = fp32 MFMA, 2 = "bf16x6" (both products as 6 bf16 partial
+ * products of exact 3-part operand splits), 3 = "bf16x3" ((hi, mid) rounded to nearest, 3 partial products), -1 =
+ * default (bf16x3 unless $ALDM_ATTN_MMA says "f32" / "bf16x6").  Returns the previous mode.                      */
 int aldm_attention_mma(int mode);
 /* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,
  * window_size = `window` <= 8, shared heads): per head h (channels [h*d, (h+1)*d), d <= 128)
@@ -255,8 +256,16 @@ int aldm_rel_attention(const float* q, const float* k, const float* v, float* ou
                        int ldq, int ldk, int ldv, int ldo, const float* emb_k, const float* emb_v, int window,
                        const float* mask, void* stream);
 /* y[r, c] = x[r, c] * s[r] (+ res[r, c] when res != NULL): the x * x_mask of the encoder's conv FFN
- * (attentions.py:406-413) and the final + positional embedding (encoders/modules.py:103)                          */
-int aldm_rowscale_add(const float* x, const float* s, const float* res, float* y, int64_t rows, int C, void* stream);
+ * (attentions.py:406-413) and the final + positional embedding (encoders/modules.py:103); divide != 0:
+ * y = x / max(s[r], 1e-12) (F.normalize with s = row norms: CLAP embeddings, clap/open_clip/model.py:745)           */
+int aldm_rowscale_add(const float* x, const float* s, const float* res, float* y, int64_t rows, int C, int divide,
+                      void* stream);
+/* T5LayerNorm (FLAN-T5 conditioner, encoders/modules.py:173-198 via transformers): y = weight * x * rsqrt(mean(x^2) + eps) */
+int aldm_rmsnorm(const float* x, float* y, int M, int C, const float* weight, float eps, void* stream);
+/* Row softmax of attention scores [B, heads, q_rows, N] with an additive bias [heads, q_rows, N] shared by the batch (T5's
+ * bucketed relative-position bias) and a key padding mask [B, N] (0 = padded key: weight 0, the reference adds finfo.min) */
+int aldm_softmax_rows_bias(const float* x, float* y, int B, int heads, int q_rows, int N, float scale, const float* bias,
+                           const float* keymask, void* stream);
 /* row softmax with pre-scale: y = softmax(scale * x) over the last dim of [M, N]
  * (model.py:220-221)                                                                        */
 int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale, void* stream);

@@ -173,3 +173,68 @@ def phoneme_input(seed: int = 7) -> torch.Tensor:
     for b, n in enumerate((T, 57, 6, 1)):
         idx[b, n:] = PHONEME["pad_token_id"]
     return idx
+
+
+# --- FLAN-T5 text conditioner ------------------------------------------------------------------
+def t5_test_config() -> dict:
+    """flan-t5-large's geometry (d_model 1024, 16 heads x 64, d_ff 2816, gated tanh-GELU, 32 buckets / distance 128) with 3
+    of its 24 layers and a 512-entry vocabulary so that fixtures and deterministic weights stay small."""
+    from .t5 import FLAN_T5_LARGE
+    c = dict(FLAN_T5_LARGE)
+    c.update(vocab_size=512, num_layers=3)
+    return c
+
+
+def t5_tokens(seed: int = 9):
+    """Token ids as the reference's tokenizer call shapes them (padding=True: right padded with id 0, EOS id 1 last,
+    modules.py:175-181): lengths 21, 7 and 1 (the empty prompt: EOS only) in a batch padded to 21."""
+    g = torch.Generator().manual_seed(seed)
+    T = 21
+    ids = torch.randint(3, 512, (3, T), generator=g)
+    mask = torch.zeros(3, T, dtype=torch.long)
+    for b, n in enumerate((21, 7, 1)):
+        ids[b, n - 1] = 1
+        ids[b, n:] = 0
+        mask[b, :n] = 1
+    return ids, mask
+
+
+def t5_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """Deterministic weights: T5's own initialisation scales (q: (d_model*d_kv)^-0.5 — it has no 1/sqrt(d) in the
+    attention — so the softmax stays in a realistic regime), O(0.5) relative-position biases."""
+    import math
+    from . import weights
+    sd = weights.make_state_dict(shapes, seed=seed)
+    for k, v in sd.items():
+        if k.endswith("SelfAttention.q.weight"):
+            sd[k] = v * (64 ** -0.5) * 3.0
+        elif "relative_attention_bias" in k:
+            sd[k] = v * math.sqrt(v.shape[1]) * 0.8
+        elif k in ("shared.weight", "encoder.embed_tokens.weight"):
+            sd[k] = v * math.sqrt(v.shape[1])
+    if "encoder.embed_tokens.weight" in sd:
+        sd["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    return sd
+
+
+# --- CLAP text tower (SURVEY §8(f) rank 2, second half) --------------------------------------------------------------
+def clap_text_test_config() -> dict:
+    """roberta-base's geometry with 2 of its 12 layers, a 600-entry vocabulary and 66 positions (fixtures stay small)."""
+    from .clap_text import ROBERTA_BASE
+    c = dict(ROBERTA_BASE)
+    c.update(vocab_size=600, num_hidden_layers=2, max_position_embeddings=66)
+    return c
+
+
+def clap_text_tokens(seed: int = 13):
+    """[3, 64] ids at padding="max_length" (modules.py:737-745): <s> = 0 first, </s> = 2 last, pad = 1; lengths 64, 9, 2."""
+    g = torch.Generator().manual_seed(seed)
+    T = 64
+    ids = torch.randint(3, 600, (3, T), generator=g)
+    mask = torch.zeros(3, T, dtype=torch.long)
+    for b, n in enumerate((64, 9, 2)):
+        ids[b, 0] = 0
+        ids[b, n - 1] = 2
+        ids[b, n:] = 1
+        mask[b, :n] = 1
+    return ids, mask

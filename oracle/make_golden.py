@@ -305,6 +305,53 @@ def gen_phoneme():
         json.dump({k: list(v) for k, v in shapes.items()}, f)
 
 
+def gen_t5():
+    """§8(f) rank 2: the REAL FlanT5HiddenState.encode_text / get_unconditional_condition (encoders/modules.py:138-198;
+    transformers T5EncoderModel underneath) at flan-t5-large's geometry with 3 layers, deterministic weights, a padded
+    token batch (the tokenizer is replaced by fixed ids: oracle/refimport.py)."""
+    cfg = cases.t5_test_config()
+    ids, mask = cases.t5_tokens()
+
+    def tok(prompt):
+        if list(prompt) == [""]:
+            return ids[2:3, :1], mask[2:3, :1]   # the empty prompt tokenises to EOS alone
+        return ids, mask
+    m = refimport.flan_t5_hidden_state(cfg, tok)
+    shapes = {k: tuple(v.shape) for k, v in m.model.state_dict().items()}
+    sd = cases.t5_state_dict(shapes)
+    m.model.load_state_dict(sd, strict=True)
+    hs, am = m(["a", "b", "c"])
+    uhs, uam = m.get_unconditional_condition(2)
+    print(f"t5: reference FlanT5HiddenState B=3 T={ids.shape[1]}: hidden {tuple(hs.shape)} std {hs.std():.3f}; uncond {tuple(uhs.shape)}")
+    save("t5_large3_b3", hidden=hs, mask=am, uncond_hidden=uhs, uncond_mask=uam)
+    with open(os.path.join(OUT, "t5_keys.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f)
+
+
+def gen_clap_text():
+    """§8(f) rank 2, second half: the CLAP text tower as clap/open_clip/model.py:513-529 builds it (transformers RobertaModel +
+    the Linear-ReLU-Linear projection) evaluated as :656-663 / :730-747 evaluate it, roberta-base geometry with 2 layers,
+    deterministic weights, padded token batch."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from transformers import RobertaConfig, RobertaModel
+    cfg = cases.clap_text_test_config()
+    branch = RobertaModel(RobertaConfig(**cfg)).eval()
+    proj = nn.Sequential(nn.Linear(768, 512), nn.ReLU(), nn.Linear(512, 512)).eval()
+    shapes = {"text_branch." + k: tuple(v.shape) for k, v in branch.state_dict().items() if v.is_floating_point()}
+    shapes.update({"text_projection." + k: tuple(v.shape) for k, v in proj.state_dict().items()})
+    sd = weights.make_state_dict(shapes, seed=0)
+    branch.load_state_dict({k[len("text_branch."):]: v for k, v in sd.items() if k.startswith("text_branch.")}, strict=False)
+    proj.load_state_dict({k[len("text_projection."):]: v for k, v in sd.items() if k.startswith("text_projection.")})
+    ids, mask = cases.clap_text_tokens()
+    x = branch(input_ids=ids, attention_mask=mask)["pooler_output"]
+    emb = F.normalize(proj(x), dim=-1)
+    print(f"clap_text: RobertaModel + projection B=3 T={ids.shape[1]}: emb {tuple(emb.shape)} pooled std {x.std():.3f}")
+    save("clap_text_base2_b3", emb=emb, pooled=x)
+    with open(os.path.join(OUT, "clap_text_keys.json"), "w") as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f)
+
+
 def _seed_all():
     import random
     random.seed(cases.E2E_SEED)
@@ -388,5 +435,9 @@ if __name__ == "__main__":
         gen_seqgen()
     if "all" in what or "phoneme" in what:
         gen_phoneme()
+    if "all" in what or "t5" in what:
+        gen_t5()
+    if "all" in what or "clap_text" in what:
+        gen_clap_text()
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")

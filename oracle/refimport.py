@@ -141,3 +141,44 @@ def phoneme_encoder(vocabs_size: int, pad_length: int, pad_token_id: int):
         sys.modules[name] = mod
         spec.loader.exec_module(mod)
     return sys.modules[name].PhonemeEncoder(vocabs_size=vocabs_size, pad_length=pad_length, pad_token_id=pad_token_id).eval()
+
+
+def flan_t5_hidden_state(cfg: dict, token_batch):
+    """The real `FlanT5HiddenState` (encoders/modules.py:113-198) with its two Hub calls replaced: `T5Config.from_pretrained`
+    returns T5Config(**cfg) and `AutoTokenizer.from_pretrained` a stand-in whose __call__ returns `token_batch`
+    (input_ids, attention_mask) — the sentencepiece model is not reachable offline, so the oracle's boundary is token ids."""
+    install()
+    import importlib.util
+    import sys
+    import types
+    from transformers import T5Config
+    path = os.path.join(REF_ROOT, "audioldm2", "latent_diffusion", "modules", "encoders", "modules.py")
+    name = "_aldm_ref_encoders_modules"
+    if name not in sys.modules:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    mod = sys.modules[name]
+
+    class _Tok:
+        def __call__(self, prompt, **kw):
+            ids, mask = token_batch(prompt)
+            return types.SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+    class _Cfg:
+        @staticmethod
+        def from_pretrained(name, *a, **k):
+            return T5Config(**cfg)
+
+    class _AutoTok:
+        @staticmethod
+        def from_pretrained(name, *a, **k):
+            return _Tok()
+    saved = mod.T5Config, mod.AutoTokenizer
+    mod.T5Config, mod.AutoTokenizer = _Cfg, _AutoTok
+    try:
+        m = mod.FlanT5HiddenState()
+    finally:
+        mod.T5Config, mod.AutoTokenizer = saved
+    return m.eval()
