@@ -47,10 +47,12 @@ def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 512 << 20) -> int:
+def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 512 << 20,
+                      even_alone: bool = False) -> int:
     """One-time weight broadcast: tensors are packed into flat buckets (few large collectives instead
-    of ~2000 tiny ones), broadcast from `src`, and copied back.  Returns bytes sent."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    of ~2000 tiny ones), broadcast from `src`, and copied back.  Returns bytes sent.  even_alone: run the
+    collectives in a 1-rank group too (tests: loads RCCL and launches its broadcast on a single GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not even_alone):
         return 0
     total = 0
     bucket: List[torch.Tensor] = []
@@ -85,10 +87,10 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_byte
     return total
 
 
-def broadcast_module(module: torch.nn.Module, src: int = 0) -> int:
+def broadcast_module(module: torch.nn.Module, src: int = 0, even_alone: bool = False) -> int:
     """Broadcast every parameter and buffer of the hot-path modules from rank `src`, then drop the
     packed-weight caches so the kernels re-pack from the received values."""
-    sent = broadcast_tensors(list(module.parameters()) + list(module.buffers()), src=src)
+    sent = broadcast_tensors(list(module.parameters()) + list(module.buffers()), src=src, even_alone=even_alone)
     for m in module.modules():
         # everything derived from the old values goes: packed weights, cached context K/V projections, captured graphs
         if hasattr(m, "invalidate_packed"):

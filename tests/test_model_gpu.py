@@ -526,3 +526,43 @@ def test_two_rank_sharded_run_equals_single_process(tmp_path):
     e = rms(sharded.astype(np.float64) - single) / rms(single)
     report(f"2-rank sharded vs single process, B={gB}, {steps} steps: wave rel rms {e:.2e}")
     assert e < 1e-5  # same kernels; only tile/grid choices differ with the per-rank batch
+
+
+def _rccl_alone_worker(rank, port, out):
+    import torch.distributed as dist
+    from audioldm2_amd import dist as adist
+    from audioldm2_amd.unet import UNetModel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)   # "nccl" IS RCCL on ROCm
+    m = UNetModel(**cases.UNET_TINY).cuda()
+    m.load_state_dict(weights.make_state_dict(weights.shapes_of(m), seed=0))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    x, t, ctxs, masks, _ = cases.unet_inputs(cases.UNET_TINY, 2, 16, 8)
+    run = lambda: m(x.cuda(), t.cuda(), context_list=[c.cuda() for c in ctxs], context_attn_mask_list=[k.cuda() for k in masks])
+    y0 = run()
+    sent = adist.broadcast_module(m, src=0, even_alone=True)   # bucketed RCCL broadcasts, then every cache invalidated
+    torch.cuda.synchronize()
+    same = all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
+    y1 = run()
+    dist.destroy_process_group()
+    torch.save({"sent": sent, "same": same, "equal": bool(torch.equal(y0, y1)), "repacked": m._pk is not None}, out)
+
+
+@pytest.mark.timeout(600)
+def test_rccl_broadcast_module_on_one_gpu(tmp_path):
+    """The weight broadcast of dist.py through RCCL itself (backend "nccl"), world size 1 on the one GPU a test box has:
+    the library loads, a communicator is created, the bucketed broadcasts launch, the parameters come back unchanged,
+    the packed / cached state is dropped and rebuilt, and the forward is bit-identical afterwards.  (N > 1 ranks over
+    xGMI need an N-GPU node: the driver's scaling run.)"""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = os.path.join(tmp_path, "rccl.pt")
+    mp.spawn(_rccl_alone_worker, args=(port, out), nprocs=1, join=True)
+    r = torch.load(out)
+    assert r["sent"] > 0 and r["same"] and r["equal"] and r["repacked"]
