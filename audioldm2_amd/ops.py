@@ -743,6 +743,66 @@ def rowscale_add(x: torch.Tensor, s: torch.Tensor, res: Optional[torch.Tensor] =
     return y
 
 
+def resample_sinc(x: torch.Tensor, kernel: torch.Tensor, down: int, up: int, width: int, out_len: int) -> torch.Tensor:
+    """Polyphase windowed-sinc resampling (torchaudio.functional.resample): x [B, T], kernel [up, taps] -> [B, out_len]."""
+    _chk(x, "resample.x"); _chk(kernel, "resample.kernel")
+    B, T = x.shape
+    assert kernel.shape[0] == up
+    y = torch.empty((B, out_len), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_resample_sinc(x.data_ptr(), kernel.data_ptr(), y.data_ptr(), B, T, out_len, down, up,
+                                          kernel.shape[1], width, _stream()), "resample_sinc")
+    return y
+
+
+def power_spec(spec: torch.Tensor, F: int, ld_out: int) -> torch.Tensor:
+    """spec [M, >= 2F] rows of [re | im] -> [M, ld_out] with re^2 + im^2 in the first F columns, zeros after."""
+    _chk(spec, "power_spec.spec")
+    M = spec.numel() // spec.shape[-1]
+    out = torch.empty((M, ld_out), device=spec.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_power_spec(spec.data_ptr(), out.data_ptr(), M, F, spec.shape[-1], ld_out, _stream()),
+             "power_spec")
+    return out
+
+
+def col_affine(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """y[..., c] = x[..., c] * scale[c] + shift[c]"""
+    _chk(x, "col_affine.x"); _chk(scale, "col_affine.scale"); _chk(shift, "col_affine.shift")
+    Cc = x.shape[-1]
+    assert scale.numel() == Cc and shift.numel() == Cc
+    y = torch.empty_like(x)
+    _l.check(_l.load().aldm_col_affine(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel() // Cc, Cc,
+                                       _stream()), "col_affine")
+    return y
+
+
+def bicubic_patchify(x: torch.Tensor, S: int, p: int) -> torch.Tensor:
+    """x [B, T, mel] -> [B, (S/p)^2, p*p]: HTSAT's reshape_wav2img + the im2col of its patch-embedding conv."""
+    _chk(x, "bicubic_patchify.x")
+    B, T, Fm = x.shape
+    out = torch.empty((B, (S // p) ** 2, p * p), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_bicubic_patchify(x.data_ptr(), out.data_ptr(), B, T, Fm, S, p, _stream()), "bicubic_patchify")
+    return out
+
+
+def token_mean(x: torch.Tensor) -> torch.Tensor:
+    """[B, L, C] -> [B, C]"""
+    _chk(x, "token_mean.x")
+    B, L, Cc = x.shape
+    y = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_token_mean(x.data_ptr(), y.data_ptr(), B, L, Cc, _stream()), "token_mean")
+    return y
+
+
+def row_cosine(a: torch.Tensor, b: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """[M, C] x [M, C] -> [M] cosine similarities (F.cosine_similarity's eps clamp)."""
+    _chk(a, "row_cosine.a"); _chk(b, "row_cosine.b")
+    assert a.shape == b.shape and a.dim() == 2
+    out = torch.empty((a.shape[0],), device=a.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_row_cosine(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1], eps, _stream()),
+             "row_cosine")
+    return out
+
+
 def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     _chk(x, "softmax.x")
     N = x.shape[-1]

@@ -110,7 +110,8 @@ def default_audioldm_config(model_name: str = "audioldm2-full", t5_len: int = 32
                 "num_res_blocks": 2, "attn_resolutions": [], "dropout": 0}
     params = {"linear_start": 0.0015, "linear_end": 0.0195, "timesteps": 1000, "parameterization": "eps",
               "first_stage_key": "fbank", "latent_t_size": 256, "latent_f_size": 16, "channels": 8,
-              "scale_by_std": True, "sampling_rate": 16000, "latent_t_per_second": 25.6}
+              "scale_by_std": True, "sampling_rate": 16000, "latent_t_per_second": 25.6,
+              "build_clap": False}  # synthetic conditioners carry no text to rank candidates against
     cond = {
         "crossattn_audiomae_generated": {
             "cond_stage_key": "all", "conditioning_key": "crossattn",
@@ -205,7 +206,8 @@ class LatentDiffusion(nn.Module):
     def __init__(self, first_stage_config, cond_stage_config=None, unet_config=None, timesteps=1000,
                  linear_start=1e-4, linear_end=2e-2, parameterization="eps", first_stage_key="fbank",
                  latent_t_size=256, latent_f_size=16, channels=8, scale_factor=1.0, scale_by_std=False,
-                 sampling_rate=16000, latent_t_per_second=25.6, device="cuda", **ignored):
+                 sampling_rate=16000, latent_t_per_second=25.6, device="cuda", build_clap=True, clap_config=None,
+                 **ignored):
         super().__init__()
         assert parameterization == "eps", "AudioLDM2 checkpoints are eps-parameterised"
         self.parameterization = parameterization
@@ -229,7 +231,15 @@ class LatentDiffusion(nn.Module):
             self.cond_stage_model_metadata[key] = {
                 "model_idx": i, "cond_stage_key": cond_stage_config[key]["cond_stage_key"],
                 "conditioning_key": cond_stage_config[key]["conditioning_key"]}
-        self.clap = None  # CLAP re-ranking (n_gen > 1) is out of scope: plug a module with cos_similarity()
+        # ddpm.py:114-120: the CLAP re-ranker of n_candidate_gen_per_text > 1 (checkpoint keys `clap.model.*`).
+        # build_clap=False (the synthetic-conditioner configs of default_audioldm_config) leaves it out; `clap_config`
+        # passes geometry overrides (tests).
+        self.clap = None
+        if build_clap:
+            from .clap import CLAPAudioEmbeddingClassifierFreev2
+            self.clap = CLAPAudioEmbeddingClassifierFreev2(pretrained_path="", enable_cuda=True,
+                                                           sampling_rate=self.sampling_rate, embed_mode="audio",
+                                                           amodel="HTSAT-base", **(clap_config or {}))
 
     @property
     def device(self):
@@ -260,10 +270,11 @@ class LatentDiffusion(nn.Module):
     # -- reference checkpoint loading ----------------------------------------------------------------
     def load_reference_state_dict(self, state_dict: Dict[str, torch.Tensor]):
         """Load the hot-path entries of a reference checkpoint (`checkpoint["state_dict"]`,
-        pipeline.py:172-174) strictly; conditioner / EMA / CLAP entries are reported, not loaded."""
+        pipeline.py:172-174) strictly; conditioner and re-ranker (`clap.*`) entries load when present; EMA and other
+        entries are reported, not loaded."""
         mine = self.state_dict()
         hot = {k: v for k, v in state_dict.items() if k in mine}
-        missing = [k for k in mine if k not in hot and not k.startswith("cond_stage_models.")]
+        missing = [k for k in mine if k not in hot and not k.startswith(("cond_stage_models.", "clap."))]
         if missing:
             raise RuntimeError(f"reference checkpoint lacks {len(missing)} hot-path tensors, e.g. {missing[:4]}")
         self.load_state_dict(hot, strict=False)
@@ -508,10 +519,10 @@ class LatentDiffusion(nn.Module):
         needs `self.clap` (a module with cos_similarity(waveform, text)); without it the candidates could only be
         generated and thrown away."""
         if n_gen > 1 and self.clap is None:
-            raise NotImplementedError("n_candidate_gen_per_text > 1 needs the CLAP re-ranker: set "
-                                      "latent_diffusion.clap to a module with cos_similarity(waveform, text) "
-                                      "(audioldm2_amd.clap.CLAPAudioEmbeddingClassifierFreev2), or pass "
-                                      "n_candidate_gen_per_text=1")
+            raise NotImplementedError("n_candidate_gen_per_text > 1 needs the CLAP re-ranker, and this model was built "
+                                      "with build_clap=False: set latent_diffusion.clap to "
+                                      "audioldm2_amd.clap.CLAPAudioEmbeddingClassifierFreev2(embed_mode='audio', ...) "
+                                      "or pass n_candidate_gen_per_text=1")
 
     @torch.no_grad()
     def generate_batch(self, batch, ddim_steps=200, ddim_eta=1.0, x_T=None, n_gen=1,
@@ -573,16 +584,14 @@ class LatentDiffusion(nn.Module):
         waveform = self.mel_spectrogram_to_waveform(mel.view(mel.shape[0], mel.shape[1], mel.shape[2]),
                                                     savepath="", bs=None, name=batch.get("fname"), save=False)
         if n_gen > 1:
-            if self.clap is None:
-                raise NotImplementedError("n_candidate_gen_per_text > 1 needs the CLAP re-ranker "
-                                          "(out of scope): set latent_diffusion.clap to a module with "
-                                          "cos_similarity(waveform, text)")
+            # ddpm.py:1554-1568: keep, per prompt, the candidate whose CLAP audio embedding is closest to the text's
             similarity = self.clap.cos_similarity(torch.FloatTensor(waveform).squeeze(1), text)
             best = []
             for i in range(B0):
                 cand = similarity[i::B0]
                 best.append(i + torch.argmax(cand).item() * B0)
             waveform = waveform[best]
+            self.last_similarity, self.last_best_index = similarity.detach().cpu(), best
         return waveform
 
 
@@ -628,11 +637,10 @@ class LatentDiffusion(nn.Module):
         waveform = self.mel_spectrogram_to_waveform(mel.view(mel.shape[0], mel.shape[1], mel.shape[2]),
                                                     savepath="", bs=None, name=batch.get("fname"), save=False)
         if n_gen > 1:
-            if self.clap is None:
-                raise NotImplementedError("n_candidate_gen_per_text > 1 needs the CLAP re-ranker (out of scope)")
-            similarity = self.clap.cos_similarity(torch.FloatTensor(waveform).squeeze(1), text)
+            similarity = self.clap.cos_similarity(torch.FloatTensor(waveform).squeeze(1), text)   # ddpm.py:1660-1670
             best = [i + torch.argmax(similarity[i::B0]).item() * B0 for i in range(B0)]
             waveform = waveform[best]
+            self.last_similarity, self.last_best_index = similarity.detach().cpu(), best
         return waveform
 
 

@@ -316,6 +316,23 @@ int aldm_mag_phase(const float* spec, float* mag, float* phase, int64_t M, int F
  * stft.py:176)                                                                              */
 int aldm_row_l2norm(const float* x, float* out, int64_t M, int F, int ld, void* stream);
 
+/* ---- CLAP audio tower glue (re-ranking of n_candidate_gen_per_text candidates, ddpm.py:1554-1568) ---------------------- */
+/* torchaudio.functional.resample's polyphase windowed-sinc FIR (encoders/modules.py:700-703): y[b, n*up + i] =
+ * sum_j xpad[b, n*down + j] * kernel[i, j] with x zero padded by `width` on the left; kernel [up, taps].           */
+int aldm_resample_sinc(const float* x, const float* kernel, float* y, int B, int T, int Tout, int down, int up, int taps,
+                       int width, void* stream);
+/* |STFT|^2 of rows [re | im] (torchlibrosa Spectrogram, power 2: clap/open_clip/htsat.py:889-897), zero padded to ld_out */
+int aldm_power_spec(const float* spec, float* out, int64_t M, int F, int ld_spec, int ld_out, void* stream);
+/* y[r, c] = x[r, c]*scale[c] + shift[c]: BatchNorm2d over the mel bins in eval mode (htsat.py:1118-1120)             */
+int aldm_col_affine(const float* x, const float* scale, const float* shift, float* y, int64_t rows, int C, void* stream);
+/* reshape_wav2img (htsat.py:1064-1090: bicubic stretch of T frames to S*S/mel, align_corners, then the fold into an S x S
+ * image) fused with the im2col of the 4x4 / stride-4 PatchEmbed conv: x [B, T, mel] -> out [B, (S/p)^2, p*p]         */
+int aldm_bicubic_patchify(const float* x, float* out, int B, int T, int mel, int S, int p, void* stream);
+/* y[b, c] = mean over the L tokens of x[b, :, c] (HTSAT "embedding", htsat.py:1034-1035)                             */
+int aldm_token_mean(const float* x, float* y, int B, int L, int C, void* stream);
+/* out[m] = cos(a[m], b[m]) with F.cosine_similarity's eps clamp (encoders/modules.py:651)                            */
+int aldm_row_cosine(const float* a, const float* b, float* out, int M, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import copy
 
+import math
+
 import torch
 
 # --- UNet ----------------------------------------------------------------------------------------
@@ -238,3 +240,42 @@ def clap_text_tokens(seed: int = 13):
         ids[b, n:] = 1
         mask[b, :n] = 1
     return ids, mask
+
+
+# --- CLAP audio tower ----------------------------------------------------------------------------
+def htsat_test_config() -> dict:
+    """HTSAT-base's geometry (embed 128, heads 4/8/16/32 = head dim 32, window 8, 256x256 image) with depths (2, 2, 2, 2)
+    instead of (2, 2, 12, 2): every kind of block (plain / shifted window, all four resolutions, patch merging) at 1/3 of
+    the weights."""
+    from .htsat import HTSAT_BASE
+    c = dict(HTSAT_BASE)
+    c["depths"] = (2, 2, 2, 2)
+    return c
+
+
+def htsat_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """Deterministic weights; relative-position tables O(0.5), BatchNorm statistics of a log-mel (mean ~ -30 dB, var ~ 100)."""
+    import math
+    from . import weights
+    sd = weights.make_state_dict(shapes, seed=seed)
+    for k, v in sd.items():
+        if k.endswith("relative_position_bias_table"):
+            sd[k] = v * math.sqrt(v.shape[1]) * 0.8
+        elif k.endswith("bn0.running_mean"):
+            sd[k] = -30.0 + 100.0 * v
+        elif k.endswith("bn0.running_var"):
+            sd[k] = 80.0 + 400.0 * v.abs()
+    return sd
+
+
+def clap_waveform(B: int = 2, seed: int = 21) -> torch.Tensor:
+    """[B, 163872] at 16 kHz (the vocoder's output length): tones + noise bursts, |x| < 1."""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(163872) / 16000.0
+    rows = []
+    for b in range(B):
+        f0 = 220.0 * (b + 1)
+        x = 0.3 * torch.sin(2 * math.pi * f0 * t) + 0.2 * torch.sin(2 * math.pi * 3.1 * f0 * t + 1.0)
+        x = x + 0.1 * torch.randn(t.shape, generator=g) * (torch.sin(2 * math.pi * 0.7 * t + b) > 0)
+        rows.append(x)
+    return torch.stack(rows).float()

@@ -34,17 +34,19 @@ def test_oracle_matches_the_transformers_fixture():
     assert torch.allclose(emb.norm(dim=-1), torch.ones(3), atol=1e-6)
 
 
-def test_product_module_has_the_reference_state_dict_and_fails_fast_on_audio_mode():
+def test_product_module_has_the_reference_state_dict():
     from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2
     sd, shapes = _sd()
-    m = CLAPAudioEmbeddingClassifierFreev2(embed_mode="text", config=cases.clap_text_test_config())
+    m = CLAPAudioEmbeddingClassifierFreev2(embed_mode="text", config=cases.clap_text_test_config(), audio_config=False)
     assert {k: tuple(v.shape) for k, v in m.model.state_dict().items()} == shapes
     m.model.load_state_dict(sd, strict=True)
-    a = CLAPAudioEmbeddingClassifierFreev2(embed_mode="audio", config=cases.clap_text_test_config())
-    with pytest.raises(NotImplementedError):
-        a(torch.zeros(1, 1, 16000))
-    with pytest.raises(NotImplementedError):
-        a.cos_similarity(torch.zeros(1, 16000), ["x"])
+    with pytest.raises(RuntimeError):                    # built without its audio branch: says so instead of guessing
+        m.model.get_audio_embedding({"waveform": torch.zeros(1, 48000)})
+    # with the audio branch (the default, like the reference's create_model) the text keys are the same ones
+    full = CLAPAudioEmbeddingClassifierFreev2(embed_mode="text", config=cases.clap_text_test_config(),
+                                              audio_config=cases.htsat_test_config())
+    have = {k: tuple(v.shape) for k, v in full.model.state_dict().items() if k.startswith("text_")}
+    assert have == shapes
 
 
 @pytest.mark.gpu
@@ -52,7 +54,8 @@ def test_hip_clap_text_tower_matches_fixture_and_replays_the_unconditional_draws
     from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2
     g = np.load(os.path.join(GOLD, "clap_text_base2_b3.npz"))
     sd, _ = _sd()
-    m = CLAPAudioEmbeddingClassifierFreev2(embed_mode="text", unconditional_prob=0.0, config=cases.clap_text_test_config())
+    m = CLAPAudioEmbeddingClassifierFreev2(embed_mode="text", unconditional_prob=0.0, config=cases.clap_text_test_config(),
+                                           audio_config=False)
     m.model.load_state_dict(sd, strict=True)
     ids, mask = cases.clap_text_tokens()
     emb = m.model.get_text_embedding({"input_ids": ids, "attention_mask": mask})
