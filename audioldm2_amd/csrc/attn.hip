@@ -67,7 +67,7 @@ __device__ __forceinline__ void split8_np(const float (&x)[8], bf16x8 (&part)[3]
 // NP (BX only): 3 = "bf16x6" (exact 3-part splits, 6 partial products), 2 = "bf16x3" ((hi, mid) rounded to nearest, 3 partial
 // products: half the MFMAs and a cheaper split — the kernel is VALU bound on the splits and the exponentials).
 template <bool HAS_MASK, int QT, bool BX = false, int NP = 3>
-__global__ __launch_bounds__(256) void attention_d32_kernel(
+__global__ __launch_bounds__(256, (QT == 1 && BX && NP == 2 && !HAS_MASK) ? 4 : 2) void attention_d32_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
     const float* __restrict__ mask, float scale, void* __restrict__ out_split, int split_c, int parts) {
@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
     const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
     if (q0 >= Lq) return;  // wave-uniform
 
-    // Q fragments: Q[q0 + 32*t + l31][h*32 + 16*lh + s], pre-scaled (rows past Lq are clamped, never stored)
+    // Q fragments: Q[q0 + 32*t + l31][h*32 + 16*lh + s], pre-scaled by scale * log2(e): the scores come out in log2 units
+    // and every exponential of the online softmax is one v_exp_f32 (rows past Lq are clamped, never stored)
+    const float qscale = scale * 1.44269504088896340736f;
     float qf[QT][16];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         for (int g = 0; g < 4; ++g) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) qf[t][4 * g + e] = x[e] * scale;
+            for (int e = 0; e < 4; ++e) qf[t][4 * g + e] = x[e] * qscale;
         }
     }
 
@@ -121,26 +123,74 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
     const float* vb = v + (int64_t)b * Lk * ldv + h * 32;
     const float* mb = HAS_MASK ? mask + (int64_t)b * Lk : nullptr;
 
-    // Branch-free tile loads: key indices are clamped to Lk-1 (the duplicates are masked to -inf
-    // below), so all 20 loads of a tile are issued back to back and waited for once.
+    // K / V / mask tiles come through raw buffer loads: the descriptor (wave uniform) carries the base and the byte range of
+    // this (batch, head) slice, the key-tile position is a scalar offset, the lane's place in the tile a loop-invariant
+    // 32-bit offset — no per-load address arithmetic on the VALU (it was 19 % of the loop's instructions) — and reads past
+    // the last key of a ragged last tile return 0 (those keys are masked to -inf below), so it needs no index clamps.
+    // All 20 loads of a tile are issued back to back and waited for once.
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, ((Lk - 1) * ldk + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, ((Lk - 1) * ldv + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_MASK ? mb : vb), 0, (HAS_MASK ? Lk : 1) * 4, 0x00020000);
+    const int koff = (l31 * ldk + 16 * lh) * 4;    // byte offsets of this lane inside a tile
+    const int voff = (4 * lh * ldv + l31) * 4;
+    const int moff = 4 * lh * 4;
     f32x4 kraw[4];
     float vf[16];
     float mk[16];
+    const int j_last = ((Lk - 1) >> 5) << 5;
     auto load_tile = [&](int j0) {
-        const int kj = min(j0 + l31, Lk - 1);
-        const float* kp = kb + (int64_t)kj * ldk + 16 * lh;
+        // The prefetch of the tile after the last one re-reads the last tile: the hardware's range check compares the lane
+        // offset with num_records - scalar offset, which wraps when the SCALAR offset alone is past the end.
+        j0 = min(j0, j_last);
+        // (readfirstlane: keep the tile offsets in scalar registers whatever the loop optimiser makes of j0)
+        const int sk = __builtin_amdgcn_readfirstlane(j0 * ldk * 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) kraw[g] = *reinterpret_cast<const f32x4*>(kp + 4 * g);
+        for (int g = 0; g < 4; ++g)
+            kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kr = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * lh, Lk - 1);
-            vf[r] = vb[(int64_t)kr * ldv + l31];
-            if (HAS_MASK) mk[r] = mb[kr];
+            const int kr = j0 + (r & 3) + 8 * (r >> 2);   // + 4*lh: in the lane offset
+            vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  rv, voff, __builtin_amdgcn_readfirstlane(kr * ldv * 4), 0));
+            if (HAS_MASK)
+                mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rm, moff, __builtin_amdgcn_readfirstlane(kr * 4), 0));
         }
     };
 
-    for (int j0 = 0; j0 < Lk; j0 += 32) {
-        load_tile(j0);
+    // one 32-key tile
+    auto key_tile = [&](int j0) {
+        // The tile's K / V (loaded during the previous tile) move out of the landing registers — as split operands on the
+        // bf16 paths — and the NEXT tile's loads are issued at once: they have this whole tile's MFMAs and softmax to
+        // land in (a prefetch past the last key reads zeros through the buffer descriptor and is never used).
+        bf16x8 kx[2][3], vx[2][3];
+        f32x4 kc[4];
+        float vc[16], mkc[16];
+        if constexpr (BX) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float x8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
+                split8_np<NP>(x8, kx[s]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
+                split8_np<NP>(x8, vx[s]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) kc[g] = kraw[g];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vc[r] = vf[r];
+        }
+        if (HAS_MASK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mkc[r] = mk[r];
+        }
+        load_tile(j0 + 32);
         // S^T tile = K Q^T: lane (query l31, half lh) gets its query's scores against keys
         // j0 + (r&3) + 8(r>>2) + 4*lh
         f32x16 st[QT];
@@ -155,46 +205,48 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
         if constexpr (BX) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                float x8[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
-                bf16x8 kx[3];
-                split8_np<NP>(x8, kx);
 #pragma unroll
                 for (int p = 0; p < NPROD; ++p)
 #pragma unroll
                     for (int t = 0; t < QT; ++t)
-                        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx[PA_[p]], qx[t][s][PB_[p]], st[t], 0, 0, 0);
+                        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx[s][PA_[p]], qx[t][s][PB_[p]], st[t], 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kraw[s >> 2][s & 3], qf[t][s], st[t], 0, 0, 0);
+                    st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[s >> 2][s & 3], qf[t][s], st[t], 0, 0, 0);
         }
 
+        // masked keys get -FLT_MAX exactly as masked_fill_(~(mask == 1), -finfo.max) does in the reference ...
+        if (HAS_MASK) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[t][r] = mkc[r] != 1.0f ? -FLT_MAX : st[t][r];
+        }
+        if (j0 + 32 > Lk) {   // ... and on the ragged last tile (wave uniform branch) keys past Lk are excluded (-inf)
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[t][r] = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= Lk ? -INFINITY : st[t][r];
+        }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            // masking: out-of-range keys are excluded (-inf); masked keys get -FLT_MAX exactly as
-            // masked_fill_(~(mask == 1), -finfo.max) does in the reference
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kj = j0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float sv = st[t][r];
-                if (HAS_MASK) sv = mk[r] != 1.0f ? -FLT_MAX : sv;
-                sv = kj >= Lk ? -INFINITY : sv;
-                st[t][r] = sv;
-                tmax = fmaxf(tmax, sv);
+                tmax = fmaxf(tmax, st[t][r]);
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float m_new = fmaxf(m_run[t], tmax);
-            const float alpha = __expf(m_run[t] - m_new);  // 0 on the first tile (m_run = -inf)
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);  // 0 on the first tile (m_run = -inf)
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(st[t][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(st[t][r] - m_new);
                 st[t][r] = pv;
                 psum += pv;
             }
@@ -208,20 +260,16 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
             // (P^T columns) of a lane half, so the pairing inside the MFMA is consistent
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                float x8[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
-                bf16x8 vx[3];
-                split8_np<NP>(x8, vx);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
+                    float x8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x8[j] = st[t][8 * s + j];
                     bf16x8 px[3];
                     split8_np<NP>(x8, px);
 #pragma unroll
                     for (int p = 0; p < NPROD; ++p)
-                        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vx[PA_[p]], px[PB_[p]], oT[t], 0, 0, 0);
+                        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vx[s][PA_[p]], px[PB_[p]], oT[t], 0, 0, 0);
                 }
             }
         } else {
@@ -229,9 +277,11 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
             for (int r = 0; r < 16; ++r)
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    oT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], st[t][r], oT[t], 0, 0, 0);
+                    oT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r], st[t][r], oT[t], 0, 0, 0);
         }
-    }
+    };
+    load_tile(0);
+    for (int j0 = 0; j0 < Lk; j0 += 32) key_tile(j0);
 
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -247,6 +297,274 @@ __global__ __launch_bounds__(256) void attention_d32_kernel(
                 for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
                 if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
                 // a head = one 32-channel block of the split image (the out-projection GEMM's pre-split A operand)
+                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
+            }
+        }
+    }
+}
+
+// ---- software-pipelined variant (bf16 paths, Lk % 32 == 0) ------------------------------------------------------------
+// A wave issues in order, and the kernel above runs a key tile as dependent phases — 12 MFMAs (S = K Q^T), ~200 VALU (mask,
+// max, exp2, sums, the P split), 12 MFMAs (O += V^T P) — so the matrix pipe idles through the softmax and the VALU through
+// the MFMAs; with two waves per SIMD in no particular phase relation the counters show the two pipes' busy times simply
+// adding up (rocprofv3 --pmc: MFMA busy 33 % + VALU 51 % + waits; profiles/r02_attn_pmc.txt).  Here every MFMA is followed
+// IN PROGRAM ORDER by a chunk of VALU work that does not depend on it (an MFMA holds the matrix pipe for 32 cycles = 16 VALU
+// issue slots), fenced with sched_barrier so the compiler keeps the order:
+//     tile j, phase 1:  MFMA  S_j = K_j Q^T               |  VALU  split P_{j-1}, split V_{j-1}, split K_{j+1}, O *= alpha_{j-1},
+//                                                          |        issue the loads of V_j and K_{j+2}
+//             phase 2:  MFMA  O += V_{j-1}^T P_{j-1}      |  VALU  softmax of S_j (mask, max, alpha_j, P_j = 2^(S_j - m_j), sums)
+// i.e. the P V product trails its softmax by one tile.  Tile 0's phase 1/2 work on P_{-1} = 0.  After the loop the last
+// tile's product is finished un-overlapped.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <bool HAS_MASK, int QT, int NP>
+__global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
+    const float* __restrict__ mask, float scale, void* __restrict__ out_split, int split_c, int parts) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
+    if (q0 >= Lq) return;  // wave-uniform
+
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
+    constexpr int PB_[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
+    constexpr int NMF = NPROD * 2 * QT;   // MFMAs of one product of a tile; MFMA i = (k-step i / (NPROD*QT), product, query tile i % QT)
+
+    // Q^T operands, pre-scaled by scale * log2(e) (scores in log2 units), k-step s covers d = 16*lh + 8*s .. + 7
+    const float qscale = scale * 1.44269504088896340736f;
+    bf16x8 qx[QT][2][3];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = min(q0 + 32 * t + l31, Lq - 1);
+        const float* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32 + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 8 * s), x1 = *reinterpret_cast<const f32x4*>(qp + 8 * s + 4);
+            float x8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x8[e] = x0[e] * qscale;
+                x8[4 + e] = x1[e] * qscale;
+            }
+            split8_np<NP>(x8, qx[t][s]);
+        }
+    }
+
+    const float* kb = k + (int64_t)b * Lk * ldk + h * 32;
+    const float* vb = v + (int64_t)b * Lk * ldv + h * 32;
+    const float* mb = HAS_MASK ? mask + (int64_t)b * Lk : nullptr;
+    const __amdgpu_buffer_rsrc_t rk =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, ((Lk - 1) * ldk + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, ((Lk - 1) * ldv + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_MASK ? mb : vb), 0, (HAS_MASK ? Lk : 1) * 4, 0x00020000);
+    const int koff = (l31 * ldk + 16 * lh) * 4;
+    const int voff = (4 * lh * ldv + l31) * 4;
+    const int moff = 4 * lh * 4;
+
+    f32x4 kraw[4];
+    float vf[16], mk[16];
+    const int j_last = Lk - 32;   // prefetches past the end re-read the last tile (see load_tile above: the range check
+                                  // does not protect against a scalar offset beyond num_records)
+    auto load_k = [&](int j0) {
+        const int sk = __builtin_amdgcn_readfirstlane(min(j0, j_last) * ldk * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
+    };
+    auto load_v = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rv, voff, __builtin_amdgcn_readfirstlane((min(j0, j_last) + (r & 3) + 8 * (r >> 2)) * ldv * 4), 0));
+    };
+    auto load_m = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rm, moff, __builtin_amdgcn_readfirstlane((min(j0, j_last) + (r & 3) + 8 * (r >> 2)) * 4), 0));
+    };
+    bf16x8 kx[2][3], kxn[2][3], vx[2][3], px[QT][2][3];
+    f32x16 oT[QT], sc[QT], pr_[QT];   // sc: scores of the tile in flight; pr_: probabilities of the previous tile (fp32)
+    float m_run[QT], l_run[QT], alpha[QT], m_new[QT], tmax[QT], psum[QT];
+
+    auto split_k_step = [&](int s, bf16x8 (&dst)[2][3]) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
+        split8_np<NP>(x8, dst[s]);
+    };
+    auto split_v_step = [&](int s) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
+        split8_np<NP>(x8, vx[s]);
+    };
+    auto split_p_step = [&](int t, int s) {
+        float x8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x8[j] = pr_[t][8 * s + j];
+        split8_np<NP>(x8, px[t][s]);
+    };
+    auto rescale = [&](int t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[t][e] *= alpha[t];
+    };
+    // phase-1 VALU work, chunk c of 3*QT + 4
+    auto chunk1 = [&](auto cc, int j) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < 2 * QT) split_p_step(c >> 1, c & 1);
+        else if constexpr (c == 2 * QT) split_v_step(0);
+        else if constexpr (c == 2 * QT + 1) {
+            split_v_step(1);
+            load_v(32 * j);                        // V_j -> split in tile j+1
+        } else if constexpr (c == 2 * QT + 2) split_k_step(0, kxn);
+        else if constexpr (c == 2 * QT + 3) {
+            split_k_step(1, kxn);
+            load_k(32 * (j + 2));                  // K_{j+2} -> split in tile j+1
+        } else if constexpr (c < 3 * QT + 4) rescale(c - (2 * QT + 4));
+    };
+    // phase-2 VALU work (softmax of sc), chunk c of 4*QT
+    auto chunk2 = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c < 4 * QT) {
+            constexpr int t = c >> 2, part = c & 3;
+            if constexpr (part == 0) {
+                if (HAS_MASK) {   // masked keys: -FLT_MAX exactly as masked_fill_(~(mask == 1), -finfo.max) in the reference
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[t][r] = mk[r] != 1.0f ? -FLT_MAX : sc[t][r];
+                }
+                float mx = sc[t][0];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, sc[t][r]);
+                tmax[t] = mx;
+            } else if constexpr (part == 1) {
+                float mx = tmax[t];
+#pragma unroll
+                for (int r = 8; r < 16; ++r) mx = fmaxf(mx, sc[t][r]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx),
+                                                                 __builtin_bit_cast(unsigned, mx), false, false);
+                mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+                m_new[t] = fmaxf(m_run[t], mx);
+                alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new[t]);   // 0 on the first tile (m_run = -inf)
+                m_run[t] = m_new[t];
+            } else {
+                float ps = part == 2 ? 0.f : psum[t];
+#pragma unroll
+                for (int r = 8 * (part - 2); r < 8 * (part - 1); ++r) {
+                    const float pvv = __builtin_amdgcn_exp2f(sc[t][r] - m_new[t]);
+                    sc[t][r] = pvv;
+                    ps += pvv;
+                }
+                psum[t] = ps;
+                if constexpr (part == 3) l_run[t] = l_run[t] * alpha[t] + ps;
+            }
+        }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma_qk = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
+        sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx[s][PA_[pr]], qx[t][s][PB_[pr]], (s == 0 && pr == 0) ? zero16 : sc[t],
+                                                        0, 0, 0);
+    };
+    auto mfma_pv = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
+        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vx[s][PA_[pr]], px[t][s][PB_[pr]], oT[t], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            oT[t][e] = 0.f;
+            pr_[t][e] = 0.f;     // P_{-1} = 0
+        }
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+        alpha[t] = 1.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vf[r] = 0.f;   // V_{-1} = 0
+
+    // prologue: K_0 split, K_1 in flight; mask tile 0 in flight
+    const int nt = Lk >> 5;
+    load_k(0);
+    if (HAS_MASK) load_m(0);
+    split_k_step(0, kx);
+    split_k_step(1, kx);
+    load_k(32);
+
+    constexpr int NC1 = 3 * QT + 4, NC2 = 4 * QT;
+    for (int j = 0; j < nt; ++j) {
+        // phase 1
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mfma_qk(ic);
+            if constexpr (i < NMF - 1) {
+                if constexpr (i < NC1) chunk1(ic, j);
+            } else {   // the last MFMA takes whatever chunks are left (QT = 1 with 3 products has fewer MFMAs than chunks)
+                static_for<NMF - 1, NC1>([&](auto cc) { chunk1(cc, j); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // phase 2
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mfma_pv(ic);
+            if constexpr (i < NMF - 1) {
+                if constexpr (i < NC2) chunk2(ic);
+            } else {
+                static_for<NMF - 1, NC2>([&](auto cc) { chunk2(cc); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (HAS_MASK) load_m(32 * (j + 1));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) pr_[t] = sc[t];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) kx[s][pr] = kxn[s][pr];
+    }
+    // the last tile's product
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        split_p_step(t, 0);
+        split_p_step(t, 1);
+        rescale(t);
+    }
+    split_v_step(0);
+    split_v_step(1);
+    static_for<0, NMF>([&](auto ic) { mfma_pv(ic); });
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + 32 * t + l31;
+        if (qi < Lq) {
+            float* op = out ? out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
+                if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
                 if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
             }
         }
@@ -292,24 +610,33 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
                  reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                "aldm_attention_d32: q/k/out must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    // 64 queries per wave (K/V fragments reused twice) when that grid still gives every CU two blocks and
-    // there are enough keys to amortise the doubled prologue: 1024x1024 self-attention 205 -> 195 us,
-    // 1024x32 cross-attention 12.0 -> 13.8 us on MI355X (tools/gpu/run9.sh)
+    // 64 queries per wave (every K / V fragment and its split reused for two query tiles) whenever there are enough keys to
+    // amortise the doubled prologue and the grid still has >= 128 blocks: 1024x1024 self-attention 85.7 us vs 106 (QT = 1),
+    // 256x256 (192 blocks) 14.7 vs 16.5 us on MI355X (profiles/r02_attn_ab.txt)
     static const int env_qt = [] {
         const char* e = getenv("ALDM_ATTN_QT");  // A/B override: 1 or 2 query tiles per wave
         return e ? atoi(e) : 0;
     }();
-    const bool qt2 = env_qt ? env_qt == 2 : (Lk >= 256 && (int64_t)cdiv(Lq, 256) * heads * B >= 512);
+    static const bool pipe = [] {   // A/B override: ALDM_ATTN_PIPE=0 runs the phase-by-phase kernel on the bf16 paths too
+        const char* e = getenv("ALDM_ATTN_PIPE");
+        return e == nullptr || e[0] != '0';
+    }();
+    const bool qt2 = env_qt ? env_qt == 2 : (Lk >= 256 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
     const int amode = g_attn_mma < 0 ? default_attn_mode() : g_attn_mma;
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
 #define ALDM_ATTN(M_, Q_, X_, P_)                                                                                 \
     hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_, P_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \
                        ldk, ldv, ldo, mask, scale, out_split, split_c, parts)
-#define ALDM_ATTN_X(M_, Q_)                         \
-    do {                                            \
-        if (amode == 3) ALDM_ATTN(M_, Q_, true, 2);  \
-        else if (amode == 2) ALDM_ATTN(M_, Q_, true, 3); \
-        else ALDM_ATTN(M_, Q_, false, 3);            \
+#define ALDM_ATTN_P(M_, Q_, P_)                                                                                        \
+    hipLaunchKernelGGL((attention_d32_pipe_kernel<M_, Q_, P_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, ldk, \
+                       ldv, ldo, mask, scale, out_split, split_c, parts)
+#define ALDM_ATTN_X(M_, Q_)                                       \
+    do {                                                          \
+        if (amode == 3 && pipe && Lk % 32 == 0) ALDM_ATTN_P(M_, Q_, 2);           \
+        else if (amode == 2 && pipe && Lk % 32 == 0) ALDM_ATTN_P(M_, Q_, 3);      \
+        else if (amode == 3) ALDM_ATTN(M_, Q_, true, 2);          \
+        else if (amode == 2) ALDM_ATTN(M_, Q_, true, 3);          \
+        else ALDM_ATTN(M_, Q_, false, 3);                         \
     } while (0)
     if (mask) {
         if (qt2) ALDM_ATTN_X(true, 2);
@@ -319,6 +646,7 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
         else ALDM_ATTN_X(false, 1);
     }
 #undef ALDM_ATTN_X
+#undef ALDM_ATTN_P
 #undef ALDM_ATTN
     ALDM_LAUNCH_CHECK("aldm_attention_d32");
     return 0;

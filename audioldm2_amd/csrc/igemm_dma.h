@@ -59,7 +59,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define ALDM_DMA_TAP_INNER 0
 #endif
 #ifndef ALDM_DMA_ABLATE
-#define ALDM_DMA_ABLATE 0  // debug builds only (tools/gpu/build_variant.sh): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads
+#define ALDM_DMA_ABLATE 0  // debug builds only (tools/gpu/build_variant.sh): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads,
+                           // 16 no epilogue (accumulators kept alive by a never-taken store), 32 K loop cut to one k-tile
 #endif
 
 // WM x 2 waves (WM = 2: 256 threads, one wave per SIMD and block; WM = 4: 512 threads, the 256-row tiles).
@@ -104,7 +105,11 @@ void igemm_dma_kernel(const IgemmK p) {
     const int nk_all = d.K >> 5;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(nk_all, kt0 + p.kt_per_split);
+#if ALDM_DMA_ABLATE & 32
+    const int nk = min(kt1 - kt0, 1);
+#else
     const int nk = kt1 - kt0;
+#endif
 
     const char* zero = reinterpret_cast<const char*>(g_dma_zero_page);
     const char* abase = reinterpret_cast<const char*>(d.a_split);
@@ -354,6 +359,17 @@ void igemm_dma_kernel(const IgemmK p) {
     mma_frags(f1);
 
     __syncthreads();   // every wave is past its last fragment read; nothing is in flight
+#if ALDM_DMA_ABLATE & 16
+    if (p.M == -12345) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d.ws[(i * NT + j) * 16 + e + threadIdx.x * 256] = acc[i][j][e];
+    }
+    return;
+#endif
     igemm_epilogue<MT, NT>(p, acc, reinterpret_cast<float*>(&smem[0]), m0, n0, wave, wm, wn, lane, 0, split);
 }
 

@@ -61,17 +61,14 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&part)[3]) {
     part[2] = u32x2{hi16_pair(u2[0], u2[1]), hi16_pair(u2[2], u2[3])};
 }
 
-// 2-part split (hi, mid), round to nearest
+// 2-part split (hi, mid), round to nearest even: gfx950 converts two floats per v_cvt_pk_bf16_f32, already packed — 2.5 VALU
+// per element against ~10 for the integer emulation (bf16_rn_bits + repacking)
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split4_rn2(const f32x4 v, u32x2 (&part)[3]) {
-    unsigned u0[4], u1[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float x = v[c];
-        u0[c] = bf16_rn_bits(x);
-        u1[c] = bf16_rn_bits(x - __builtin_bit_cast(float, u0[c]));
-    }
-    part[0] = u32x2{hi16_pair(u0[0], u0[1]), hi16_pair(u0[2], u0[3])};
-    part[1] = u32x2{hi16_pair(u1[0], u1[1]), hi16_pair(u1[2], u1[3])};
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const bf16x4 m = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+    part[0] = __builtin_bit_cast(u32x2, h);
+    part[1] = __builtin_bit_cast(u32x2, m);
     part[2] = u32x2{0u, 0u};
 }
 

@@ -21,6 +21,15 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MOD_TOL = 2e-4
 
 
+def batch_tol():
+    """Agreement of the same computation at two batch sizes: the launches pick different tiles / split-K / attention
+    variants, i.e. different fp32 summation orders (1e-7-level differences).  In the default bf16x3 mode those move the
+    round-to-nearest (hi, mid) operand splits of later layers by an ulp of `mid` here and there, so the two runs agree to
+    that mode's own noise floor (per-GEMM 4e-6 rms) rather than to 1e-5."""
+    from audioldm2_amd import ops
+    return 5e-5 if ops.MMA_MODE == "bf16x3" else 1e-5
+
+
 def gold(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
@@ -115,7 +124,7 @@ def test_unet_full_vs_oracle_batch8_properties():
         assert rel(out[sl], ref) < MOD_TOL
         alone = m(x[sl].cuda(), t[sl].cuda(), context_list=cu([c[sl] for c in ctxs]),
                   context_attn_mask_list=cu([mm[sl] for mm in masks]))
-        assert rel(alone, out[sl]) < 1e-5  # same kernels; only tile/grid shapes differ
+        assert rel(alone, out[sl]) < batch_tol()  # same kernels; only tile/grid shapes differ
 
 
 def test_unet_full_batch16_vs_pytorch_rocm_eager():
@@ -379,7 +388,7 @@ def test_cfg_batched_equals_two_passes_and_graph_equals_eager(ld):
     eps2 = ld.apply_model_cfg(x, t.float().repeat(2).cuda(), cond, uncond)
     e_u = ld.apply_model(x, t.cuda(), uncond)
     e_c = ld.apply_model(x, t.cuda(), cond)
-    assert rel(eps2[0], e_u) < 1e-5 and rel(eps2[1], e_c) < 1e-5
+    assert rel(eps2[0], e_u) < batch_tol() and rel(eps2[1], e_c) < batch_tol()
     os.environ["ALDM_NO_GRAPH"] = "1"
     try:
         eager = _generate(ld, 2, 4)
@@ -438,7 +447,7 @@ def test_other_baseline_configs_run_end_to_end(model_name, wave_len):
     t = torch.tensor([301.0, 301.0]).cuda()
     eps2 = m.apply_model_cfg(x, t.repeat(2), cond, uncond)
     e_u, e_c = m.apply_model(x, t, uncond), m.apply_model(x, t, cond)
-    assert rel(eps2[0], e_u) < 1e-5 and rel(eps2[1], e_c) < 1e-5
+    assert rel(eps2[0], e_u) < batch_tol() and rel(eps2[1], e_c) < batch_tol()
     del m
     torch.cuda.empty_cache()
 
@@ -525,7 +534,7 @@ def test_two_rank_sharded_run_equals_single_process(tmp_path):
     assert sharded.shape == single.shape == (gB, 1, 163872)
     e = rms(sharded.astype(np.float64) - single) / rms(single)
     report(f"2-rank sharded vs single process, B={gB}, {steps} steps: wave rel rms {e:.2e}")
-    assert e < 1e-5  # same kernels; only tile/grid choices differ with the per-rank batch
+    assert e < batch_tol()  # same kernels; only tile/grid choices differ with the per-rank batch
 
 
 def _rccl_alone_worker(rank, port, out):
