@@ -60,7 +60,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 #ifndef ALDM_DMA_ABLATE
 #define ALDM_DMA_ABLATE 0  // debug builds only (tools/gpu/build_variant.sh): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads,
-                           // 16 no epilogue (accumulators kept alive by a never-taken store), 32 K loop cut to one k-tile
+                           // 16 no epilogue (accumulators kept alive by a never-taken store), 32 K loop cut to one k-tile,
+                           // 64 the epilogue computes but never stores
 #endif
 
 // WM x 2 waves (WM = 2: 256 threads, one wave per SIMD and block; WM = 4: 512 threads, the 256-row tiles).

@@ -7,6 +7,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef ALDM_DMA_ABLATE
+#define ALDM_DMA_ABLATE 0  // debug builds only, see igemm_dma.h; bit 64: the epilogue computes but never stores
+#endif
+
 namespace aldm {
 
 struct IgemmK {
@@ -118,6 +122,7 @@ template <int MT, int NT>
 __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT][NT], float* lds, int m0, int n0,
                                                int wave, int wm, int wn, int lane, int z, int split) {
     const aldm_igemm_desc& d = p.d;
+    const bool epi_st = (ALDM_DMA_ABLATE & 64) ? p.M == -12345 : true;   // (ablation builds: compute, never store)
     constexpr int SP = NT * 32 + 4;   // staging row pitch (floats); +4 keeps 16-byte alignment
     constexpr int C4 = NT * 8;        // float4 per staged row
     constexpr int RPI = 64 / C4;      // rows covered by one wave-wide float4 read
@@ -170,7 +175,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
 #pragma unroll
                     for (int c = 0; c < 4; ++c) xv[c] *= act_apply(xg[c], gate_act, 0.f);
                     const int m = m0 + (wm * MT + i) * 32 + r;
-                    if (m < p.M && cok) {
+                    if (m < p.M && cok && epi_st) {
                         if (go) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;
                         if (simg) split_store4(simg, m, d.out_split_c, ncol_o, xv, d.split_parts);
                     }
@@ -220,7 +225,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
             rowoff[it] = ok ? orow * ld_out + ncol : 0;
             srow[it] = orow;
             rboff[it] = ok ? b * p.rb_ld + ncol : 0;
-            okmask |= (ok ? 1u : 0u) << it;
+            okmask |= ((ok && epi_st) ? 1u : 0u) << it;
         }
         if (split_out) {
 #pragma unroll

@@ -1,6 +1,7 @@
 // norm.hip — GroupNorm statistics (-> per-(sample, channel) affine consumed by the igemm prologue),
 // LayerNorm, row softmax.  All HBM-bound: one coalesced 16-byte read per element, fp32 math,
 // deterministic reduction order (no atomics).
+#include <stdlib.h>
 #include "igemm_epilogue.h"
 
 namespace aldm {
@@ -34,8 +35,9 @@ __device__ __forceinline__ void gn_merge(double& n, double& mean, double& m2, do
     n = nt;
 }
 
-// FUSED: one block covers a whole (small) sample, keeps the group sums in LDS and finalises in the
-// same launch — for the deep UNet levels (P <= 256 pixels) the two-launch form is pure latency.
+// FUSED: statistics AND the affine in one launch, for samples small enough that the two-launch form is pure latency: block
+// (gs, b) owns `gpb` whole groups of sample b — groups are independent, so it reads all P pixels of its channel slab, merges
+// and finalises alone.  (Round 1 used one block per sample: 16 blocks on 256 CUs, 13 us for 100-800 KB.)
 template <bool FUSED>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x1,
                                                          const float* __restrict__ x2, int P,
@@ -43,24 +45,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                                                          int chunk_px, float* __restrict__ ws, float eps,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         float* __restrict__ scale, float* __restrict__ shift) {
+                                                         float* __restrict__ scale, float* __restrict__ shift, int gpb) {
     const int C = C1 + C2;
-    const int C4 = C >> 2;
     const int Cg4 = (C / G) >> 2;
     const int b = blockIdx.y;
-    const int chunk = blockIdx.x;
+    const int chunk = FUSED ? 0 : blockIdx.x;
+    const int g_lo = FUSED ? blockIdx.x * gpb : 0;         // first group of this block; it owns groups g_lo .. g_lo + gpb - 1
+    const int c4_lo = g_lo * Cg4, C4 = c4_lo + gpb * Cg4;  // its float4 columns [c4_lo, C4)
     const int p0 = chunk * chunk_px;
     const int p1 = min(P, p0 + chunk_px);
     const int tid = threadIdx.x;
     const int tx = tid % cols, ty = tid / cols;
     __shared__ GnPart ps[256];
-    // columns handled in passes of `cols` (cols = min(C4, 256))
-    const int npass = (C4 + cols - 1) / cols;
-    __shared__ double gacc[64][3];   // running (n, mean, M2) per group of this block
+    // columns handled in passes of `cols` (cols = min(columns of the block, 256))
+    const int npass = (C4 - c4_lo + cols - 1) / cols;
+    __shared__ double gacc[64][3];   // running (n, mean, M2) per group of this block (index: g - g_lo)
     if (tid < 64) gacc[tid][0] = gacc[tid][1] = gacc[tid][2] = 0.0;
     __syncthreads();
     for (int cp = 0; cp < npass; ++cp) {
-        const int c4 = cp * cols + tx;
+        const int c4 = c4_lo + cp * cols + tx;
         GnPart part = {0.f, 0.f, 0.f};
         if (ty < rows && c4 < C4 && p0 + ty < p1) {
             const int c = c4 << 2;
@@ -106,23 +109,54 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             part.mean = pivot + md;
             part.m2 = fmaxf(ss - s * md, 0.f);
         }
+        if constexpr (FUSED) {
+            // the block owns few groups (gpb <= 4) spread over all 256 threads: per group, a butterfly of Chan merges over the
+            // wave (fixed pattern -> deterministic), then thread 0 folds the four wave results in order
+            __shared__ double wred[4][3];
+            const int mygl = (c4 - c4_lo) / Cg4;
+            for (int gl = 0; gl < gpb; ++gl) {
+                const bool mine = part.n > 0.f && mygl == gl;
+                double n = mine ? (double)part.n : 0.0, mean = mine ? (double)part.mean : 0.0, m2 = mine ? (double)part.m2 : 0.0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), m2b = __shfl_xor(m2, o);
+                    gn_merge(n, mean, m2, nb, mb, m2b);
+                }
+                if ((tid & 63) == 0) {
+                    wred[tid >> 6][0] = n;
+                    wred[tid >> 6][1] = mean;
+                    wred[tid >> 6][2] = m2;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    double an = gacc[gl][0], am = gacc[gl][1], a2 = gacc[gl][2];
+                    for (int w = 0; w < 4; ++w) gn_merge(an, am, a2, wred[w][0], wred[w][1], wred[w][2]);
+                    gacc[gl][0] = an;
+                    gacc[gl][1] = am;
+                    gacc[gl][2] = a2;
+                }
+                __syncthreads();
+            }
+            continue;
+        }
         ps[tid] = part;
         __syncthreads();
-        // groups touched by this column pass: c4 in [cp*cols, cp*cols+cols)
+        // groups touched by this column pass: c4 in [c4_lo + cp*cols, c4_lo + cp*cols + cols)
         // one thread per group merges, in fixed order, all (tx, ty) of that group.
-        if (tid < G) {
-            const int g = tid;
-            const int lo = max(g * Cg4, cp * cols), hi = min((g + 1) * Cg4, min(C4, (cp + 1) * cols));
+        if (tid < gpb) {
+            const int g = g_lo + tid;
+            const int base = c4_lo + cp * cols;
+            const int lo = max(g * Cg4, base), hi = min((g + 1) * Cg4, min(C4, base + cols));
             if (lo < hi) {
-                double n = gacc[g][0], mean = gacc[g][1], m2 = gacc[g][2];
+                double n = gacc[tid][0], mean = gacc[tid][1], m2 = gacc[tid][2];
                 for (int yy = 0; yy < rows; ++yy)
                     for (int cc = lo; cc < hi; ++cc) {
-                        const GnPart& t = ps[yy * cols + (cc - cp * cols)];
+                        const GnPart& t = ps[yy * cols + (cc - base)];
                         gn_merge(n, mean, m2, (double)t.n, (double)t.mean, (double)t.m2);
                     }
-                gacc[g][0] = n;
-                gacc[g][1] = mean;
-                gacc[g][2] = m2;
+                gacc[tid][0] = n;
+                gacc[tid][1] = mean;
+                gacc[tid][2] = m2;
             }
         }
         __syncthreads();
@@ -130,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     if (FUSED) {
         const int Cg = C / G;
         __shared__ float fin[64][2];
-        if (tid < G) {
+        if (tid < gpb) {
             const double n = gacc[tid][0];
             double var = n > 0.0 ? gacc[tid][2] / n : 0.0;
             if (var < 0.0) var = 0.0;
@@ -138,8 +172,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             fin[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
         }
         __syncthreads();
-        for (int c = tid; c < C; c += 256) {
-            const int g = c / Cg;
+        for (int c = g_lo * Cg + tid; c < (g_lo + gpb) * Cg; c += 256) {
+            const int g = c / Cg - g_lo;
             const float sc = fin[g][1] * (gamma ? gamma[c] : 1.f);
             scale[(int64_t)b * C + c] = sc;
             shift[(int64_t)b * C + c] = (beta ? beta[c] : 0.f) - fin[g][0] * sc;
@@ -203,9 +237,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // ---- LayerNorm: one wave64 per R rows, rows kept in registers (C <= 2048), exact two-pass --------
-// All R rows' 16-byte loads are issued before the first reduction: a wave that loads one 1 KiB row and
-// then runs two dependent shuffle trees is latency bound (1.9 TB/s measured); R independent rows in
-// flight per wave hide that latency.
+// All R rows' 16-byte loads are issued before the first reduction.  Which R is best is an occupancy question, measured
+// (tools/ln_bench.py): with few rows (round 1: M = 2048) R = 4 independent rows per wave hid the latency of the two dependent
+// shuffle trees; at the UNet's M = 4096..16384 one row per wave — four times the waves — does it better.
 constexpr int LN_MAXV = 8;
 
 // RMS = true: T5LayerNorm (transformers T5: y = w * x * rsqrt(mean(x^2) + eps), no mean subtraction, no bias).
@@ -364,12 +398,25 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
     int cols, rows, chunk_px, chunks;
     gn_geometry(P, C, &cols, &rows, &chunk_px, &chunks);
     hipStream_t st = (hipStream_t)stream;
-    if ((int64_t)P * C <= 200 * 1024) {  // small sample (deep UNet levels): one block, one launch
-        hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(1, B), dim3(256), 0, st, x1, x2, P, C1, C2, G, cols,
-                           rows, P, ws, eps, gamma, beta, scale, shift);
+    static const int64_t fused_max = [] {   // A/B override: largest sample (elements) handled by the one-launch form
+        const char* e = getenv("ALDM_GN_FUSED_MAX");
+        return e ? (int64_t)atoll(e) : (int64_t)1 << 20;
+    }();
+    // group slices per sample: enough blocks to cover the chip (>= 256 / B), each owning gpb = G / gs whole groups
+    int gs = 1;
+    while (gs < G && gs * B < 256 && G % (gs * 2) == 0) gs *= 2;
+    const int gpb = G / gs;
+    // one launch, blocks own whole groups: up to 1024 pixels per sample (measured, tools/gn_bench.py / profiles/r02_gn_bench.txt:
+    // 6.6-8.5 us against 7.9-12.4 for the chunked two-launch form; at 4096 pixels a block's narrow channel slab reads 32 bytes
+    // per 512-byte row and loses, 24.6 vs 12.0 us)
+    if ((int64_t)P * C <= fused_max && P <= 1024 && gpb <= 4) {
+        const int c4b = gpb * (C / G) / 4;
+        const int fcols = c4b < 256 ? c4b : 256, frows = 256 / fcols;
+        hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(gs, B), dim3(256), 0, st, x1, x2, P, C1, C2, G, fcols,
+                           frows, P, ws, eps, gamma, beta, scale, shift, gpb);
     } else {
         hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, B), dim3(256), 0, st, x1, x2, P, C1, C2, G,
-                           cols, rows, chunk_px, ws, eps, gamma, beta, scale, shift);
+                           cols, rows, chunk_px, ws, eps, gamma, beta, scale, shift, G);
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, ws, chunks, P, C, G, eps, gamma,
                            beta, scale, shift);
     }
@@ -395,9 +442,21 @@ static int layernorm_launch(const float* x, float* y, void* y_split, int parts, 
                                C, gamma, beta, eps, y_split, parts);                                                \
     } while (0)
     const int nv = cdiv(C / 4, 64);
-    if (nv <= 1) ALDM_LN(1, 4);
-    else if (nv <= 2) ALDM_LN(2, 4);
-    else if (nv <= 4) ALDM_LN(4, 2);
+    static const int env_r = [] {   // A/B override (tools/ln_bench.py): rows per wave for C <= 512
+        const char* e = getenv("ALDM_LN_R");
+        return e ? atoi(e) : 0;
+    }();
+    // one row per wave up to C = 512: more, shorter waves hide the load latency better than 4 rows in flight per wave
+    // (M = 16384, C = 256: 9.2 -> 7.9 us; M = 4096, C = 384: 6.9 -> 4.6 us, profiles/r02_ln_bench.txt)
+    if (nv <= 1) {
+        if (env_r == 4) ALDM_LN(1, 4);
+        else if (env_r == 2) ALDM_LN(1, 2);
+        else ALDM_LN(1, 1);
+    } else if (nv <= 2) {
+        if (env_r == 4) ALDM_LN(2, 4);
+        else if (env_r == 2) ALDM_LN(2, 2);
+        else ALDM_LN(2, 1);
+    } else if (nv <= 4) ALDM_LN(4, 2);
     else ALDM_LN(8, 1);
 #undef ALDM_LN
     ALDM_LAUNCH_CHECK(name);
