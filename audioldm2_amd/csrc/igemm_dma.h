@@ -80,7 +80,7 @@ void igemm_dma_kernel(const IgemmK p) {
     constexpr int NPROD = NP == 3 ? 6 : 3;    // bf16 partial products per fp32 product
     static_assert(NP == 2 || NP == 3, "2 or 3 parts");
     static_assert(BM % (16 * NW) == 0 && (4 * NP * (BN / 64)) % NW == 0, "DMA chunks must divide among the waves");
-    static_assert(NST >= 2 && NST <= 4 && (NST - 1) * D <= 63, "ring depth / vmcnt range");
+    static_assert(NST >= 2 && NST <= 8 && (NST - 1) * D <= 63, "ring depth / vmcnt range");
     static_assert(NW * 32 * (NT * 32 + 4) * 4 <= NST * STG * 16, "epilogue staging must fit the ring");
     __shared__ u32x4 smem[NST * STG];   // the ONLY LDS object (a second one makes hipcc drain vmcnt before every ds_read)
 
@@ -299,10 +299,14 @@ void igemm_dma_kernel(const IgemmK p) {
     };
     // wait until at most `n` k-tiles of this thread's DMA are still in flight (n is wave uniform)
     auto wait_tiles = [&](int n) {
+        constexpr int MX = NST - 1;   // at most NST - 1 tiles are ever in flight
         if (n <= 0) wait_vmcnt<0>();
         else if (n == 1) wait_vmcnt<D>();
-        else if (n == 2) wait_vmcnt<(NST > 2 ? 2 : 1) * D>();
-        else wait_vmcnt<(NST > 3 ? 3 : 1) * D>();
+        else if (n == 2) wait_vmcnt<(MX >= 2 ? 2 : MX) * D>();
+        else if (n == 3) wait_vmcnt<(MX >= 3 ? 3 : MX) * D>();
+        else if (n == 4) wait_vmcnt<(MX >= 4 ? 4 : MX) * D>();
+        else if (n == 5) wait_vmcnt<(MX >= 5 ? 5 : MX) * D>();
+        else wait_vmcnt<(MX >= 6 ? 6 : MX) * D>();
     };
 
     // ---- K loop ----------------------------------------------------------------------------------------------

@@ -8,8 +8,9 @@ namespace aldm {
 bool igemm_dma_config_ok(int BM, int BN, int nst, int parts) {
     if (BM == 256 && BN == 128) return parts == 3 ? nst == 2 : (nst == 2 || nst == 3);
     if (BM == 128 && BN == 128) return parts == 3 ? (nst == 2 || nst == 3) : (nst == 2 || nst == 4);
-    if ((BM == 64 && BN == 128) || (BM == 128 && BN == 64)) return nst == 2 || nst == 4;
-    if (BM == 64 && BN == 64) return nst == 2 || nst == 3;
+    // (6-deep rings, 2-part images only: the small-M launches run one block per CU and are bound by the LDS-DMA latency)
+    if ((BM == 64 && BN == 128) || (BM == 128 && BN == 64)) return nst == 2 || nst == 4 || (nst == 6 && parts == 2);
+    if (BM == 64 && BN == 64) return nst == 2 || nst == 3 || (nst == 6 && parts == 2);
     return false;
 }
 
@@ -34,10 +35,13 @@ int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t 
         else if (BM == 256 && BN == 128 && nst == 2) ALDM_DMA8(256, 128, 2, 2);
         else if (BM == 128 && BN == 128 && nst == 4) ALDM_DMA(128, 128, 4, 2);
         else if (BM == 128 && BN == 128 && nst == 2) ALDM_DMA(128, 128, 2, 2);
+        else if (BM == 64 && BN == 128 && nst == 6) ALDM_DMA(64, 128, 6, 2);
         else if (BM == 64 && BN == 128 && nst == 4) ALDM_DMA(64, 128, 4, 2);
         else if (BM == 64 && BN == 128 && nst == 2) ALDM_DMA(64, 128, 2, 2);
+        else if (BM == 128 && BN == 64 && nst == 6) ALDM_DMA(128, 64, 6, 2);
         else if (BM == 128 && BN == 64 && nst == 4) ALDM_DMA(128, 64, 4, 2);
         else if (BM == 128 && BN == 64 && nst == 2) ALDM_DMA(128, 64, 2, 2);
+        else if (BM == 64 && BN == 64 && nst == 6) ALDM_DMA(64, 64, 6, 2);
         else if (BM == 64 && BN == 64 && nst == 3) ALDM_DMA(64, 64, 3, 2);
         else if (BM == 64 && BN == 64 && nst == 2) ALDM_DMA(64, 64, 2, 2);
         else return -1;

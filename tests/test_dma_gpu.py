@@ -97,8 +97,8 @@ def test_conv_on_split_operand(ops, B, C, N, H, W, k, s, p, up):
 
 _TILES = {"bf16x6": [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2),
                      (64, 64, 3), (64, 64, 2)],
-          "bf16x3": [(256, 128, 2), (256, 128, 3), (128, 128, 4), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4),
-                     (128, 64, 2), (64, 64, 3), (64, 64, 2)]}
+          "bf16x3": [(256, 128, 2), (256, 128, 3), (128, 128, 4), (128, 128, 2), (64, 128, 6), (64, 128, 4), (64, 128, 2),
+                     (128, 64, 6), (128, 64, 4), (128, 64, 2), (64, 64, 6), (64, 64, 3), (64, 64, 2)]}
 
 
 @pytest.mark.parametrize("mode,bm,bn,st", [(m, *t) for m, ts in _TILES.items() for t in ts])

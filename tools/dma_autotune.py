@@ -20,8 +20,8 @@ from audioldm2_amd import ops  # noqa: E402
 
 CFGS = {3: [(256, 128, 2), (128, 128, 3), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2), (64, 64, 3),
             (64, 64, 2)],
-        2: [(256, 128, 3), (256, 128, 2), (128, 128, 4), (128, 128, 2), (64, 128, 4), (64, 128, 2), (128, 64, 4), (128, 64, 2),
-            (64, 64, 3), (64, 64, 2)]}
+        2: [(256, 128, 3), (256, 128, 2), (128, 128, 4), (128, 128, 2), (64, 128, 6), (64, 128, 4), (64, 128, 2), (128, 64, 6),
+            (128, 64, 4), (128, 64, 2), (64, 64, 6), (64, 64, 3), (64, 64, 2)]}
 SPLITS = [1, 2, 3, 4, 6, 8]
 PARTS = 2 if os.environ.get("ALDM_MMA") == "bf16x3" else 3
 SUFFIX = ",dma2" if PARTS == 2 else ",dma"
