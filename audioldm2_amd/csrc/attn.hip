@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256, (QT == 1 && BX && NP == 2 && !HAS_MASK) ? 4 : 
             kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kr = j0 + (r & 3) + 8 * (r >> 2);   // + 4*lh: in the lane offset
+            // (+ 4*lh rows: in the lane offset.  The SCALAR part is clamped to the last key: the range check only protects
+            // offsets whose scalar part is inside the buffer; rows past Lk then come back as 0 / are masked below)
+            const int kr = min(j0 + (r & 3) + 8 * (r >> 2), Lk - 1);
             vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                   rv, voff, __builtin_amdgcn_readfirstlane(kr * ldv * 4), 0));
             if (HAS_MASK)
