@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256, (QT == 1 && BX && NP == 2 && !HAS_MASK) ? 4 : 
 
     // K / V / mask tiles come through raw buffer loads: the descriptor (wave uniform) carries the base and the byte range of
     // this (batch, head) slice, the key-tile position is a scalar offset, the lane's place in the tile a loop-invariant
-    // 32-bit offset — no per-load address arithmetic on the VALU (it was 19 % of the loop's instructions) — and reads past
-    // the last key of a ragged last tile return 0 (those keys are masked to -inf below), so it needs no index clamps.
+    // 32-bit offset — no per-load address arithmetic on the VALU (it was 19 % of the loop's instructions).
     // All 20 loads of a tile are issued back to back and waited for once.
     const __amdgpu_buffer_rsrc_t rk =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, ((Lk - 1) * ldk + 32) * 4, 0x00020000);
@@ -142,24 +141,38 @@ __global__ __launch_bounds__(256, (QT == 1 && BX && NP == 2 && !HAS_MASK) ? 4 : 
     float mk[16];
     const int j_last = ((Lk - 1) >> 5) << 5;
     auto load_tile = [&](int j0) {
-        // The prefetch of the tile after the last one re-reads the last tile: the hardware's range check compares the lane
-        // offset with num_records - scalar offset, which wraps when the SCALAR offset alone is past the end.
+        // The prefetch of the tile after the last one re-reads the last tile.  The descriptor's range check is NOT relied on
+        // for correctness (it compares the lane offset with num_records - scalar offset, which protects nothing once the
+        // scalar part is itself past the end, and 4 rows of a lane offset can run past a short buffer unnoticed): every
+        // offset formed here addresses a key < Lk.
         j0 = min(j0, j_last);
-        // (readfirstlane: keep the tile offsets in scalar registers whatever the loop optimiser makes of j0)
-        const int sk = __builtin_amdgcn_readfirstlane(j0 * ldk * 4);
+        if (j0 + 32 <= Lk) {   // full tile (wave uniform): scalar tile offset + loop-invariant lane offset
+            // (readfirstlane: keep the tile offsets in scalar registers whatever the loop optimiser makes of j0)
+            const int sk = __builtin_amdgcn_readfirstlane(j0 * ldk * 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
+            for (int g = 0; g < 4; ++g)
+                kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // (+ 4*lh rows: in the lane offset.  The SCALAR part is clamped to the last key: the range check only protects
-            // offsets whose scalar part is inside the buffer; rows past Lk then come back as 0 / are masked below)
-            const int kr = min(j0 + (r & 3) + 8 * (r >> 2), Lk - 1);
-            vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                  rv, voff, __builtin_amdgcn_readfirstlane(kr * ldv * 4), 0));
-            if (HAS_MASK)
-                mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rm, moff, __builtin_amdgcn_readfirstlane(kr * 4), 0));
+            for (int r = 0; r < 16; ++r) {
+                const int kr = j0 + (r & 3) + 8 * (r >> 2);   // + 4*lh rows: in the lane offset
+                vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rv, voff, __builtin_amdgcn_readfirstlane(kr * ldv * 4), 0));
+                if (HAS_MASK)
+                    mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rm, moff, __builtin_amdgcn_readfirstlane(kr * 4), 0));
+            }
+        } else {               // ragged last tile: key indices clamped per lane (the duplicates are masked to -inf below)
+            const int kj = min(j0 + l31, Lk - 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                kraw[g] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, (kj * ldk + 16 * lh + 4 * g) * 4, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = min(j0 + (r & 3) + 8 * (r >> 2) + 4 * lh, Lk - 1);
+                vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, (kr * ldv + l31) * 4, 0, 0));
+                if (HAS_MASK) mk[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, kr * 4, 0, 0));
+            }
         }
     };
 
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256, (QT == 1 && BX && NP == 2 && !HAS_MASK) ? 4 : 
     auto key_tile = [&](int j0) {
         // The tile's K / V (loaded during the previous tile) move out of the landing registers — as split operands on the
         // bf16 paths — and the NEXT tile's loads are issued at once: they have this whole tile's MFMAs and softmax to
-        // land in (a prefetch past the last key reads zeros through the buffer descriptor and is never used).
+        // land in (a prefetch past the last tile re-reads the last tile and is never used).
         bf16x8 kx[2][3], vx[2][3];
         f32x4 kc[4];
         float vc[16], mkc[16];
@@ -379,8 +392,8 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
 
     f32x4 kraw[4];
     float vf[16], mk[16];
-    const int j_last = Lk - 32;   // prefetches past the end re-read the last tile (see load_tile above: the range check
-                                  // does not protect against a scalar offset beyond num_records)
+    const int j_last = Lk - 32;   // prefetches past the end re-read the last tile (see load_tile above: the descriptor's
+                                  // range check is not relied on; with Lk % 32 == 0 every offset formed here is < Lk)
     auto load_k = [&](int j0) {
         const int sk = __builtin_amdgcn_readfirstlane(min(j0, j_last) * ldk * 4);
 #pragma unroll

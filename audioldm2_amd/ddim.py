@@ -15,6 +15,7 @@ Differences that matter on MI355X:
 """
 from __future__ import annotations
 
+import gc
 import os
 
 import numpy as np
@@ -57,6 +58,14 @@ class GraphStepper:
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
+                # No cyclic garbage collection while the stream is capturing: a collection that happens to run inside the
+                # capture can finalise objects of EARLIER jobs (an evicted step graph, a noise feed's side stream and pinned
+                # buffers) whose destructors call HIP functions that are illegal during capture — the C++ destructor then
+                # throws and the process aborts ("Fatal Python error: Aborted ... Garbage-collecting" a few tests into a
+                # long session, at a different place every time).  Collect first, then hold the collector off.
+                gc.collect()
+                gc_was_on = gc.isenabled()
+                gc.disable()
                 try:
                     # thread_local: other threads (e.g. the RCCL watchdog of a multi-GPU run) may keep
                     # calling HIP while this thread captures
@@ -69,13 +78,32 @@ class GraphStepper:
                           file=sys.stderr, flush=True)
                     self.use_graph = False
                     torch.cuda.synchronize()
+                    if gc_was_on:
+                        gc.enable()
                     self.fn()
                     self.calls += 1
                     return
+                finally:
+                    if gc_was_on:
+                        gc.enable()
             self.graph.replay()
         else:
             self.fn()
         self.calls += 1
+
+
+def drop_graph_entries(cache: dict) -> None:
+    """Evict cached step graphs NOW, by reference counting: an entry is a reference cycle (entry -> stepper -> step closure ->
+    entry), so simply forgetting it leaves the HIP graph, its private memory pool and its static buffers to the cyclic
+    collector — which may then run in the middle of the next capture (see GraphStepper).  Breaking the cycle here frees
+    them at a point where no stream is capturing."""
+    for ent in list(cache.values()):
+        rs = ent.get("run_step")
+        if rs is not None:
+            rs.fn = None
+            rs.graph = None
+        ent.clear()
+    cache.clear()
 
 
 class _NoiseFeed:
@@ -319,7 +347,7 @@ class DDIMSampler(object):
         ent = unet._graph_cache.get(key) if can_cache else None
         if ent is not None and ent.get("kv") is None:
             # the entry never got as far as recording the K/V buffers its graph reads (e.g. an interrupted first run)
-            unet._graph_cache.pop(key, None)
+            drop_graph_entries(unet._graph_cache)
             ent = None
         if ent is not None:
             for dst, src in zip(ent["prepared"]["ctxs"] + ent["prepared"]["masks"],
@@ -352,7 +380,7 @@ class DDIMSampler(object):
                 x_c.copy_(e["x_next"])
             ent["run_step"] = GraphStepper(step, self.use_graph)
             if can_cache:
-                unet._graph_cache.clear()  # one geometry at a time: the graph pins its activation pool
+                drop_graph_entries(unet._graph_cache)  # one geometry at a time: the graph pins its activation pool
                 unet._graph_cache[key] = ent
         x_cur, pred_x0, t_cur, coef_cur, noise_cur = (ent["x_cur"], ent["pred_x0"], ent["t_cur"], ent["coef_cur"],
                                                       ent["noise_cur"])

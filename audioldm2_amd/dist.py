@@ -100,7 +100,8 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, even_alone: bool = F
         if hasattr(m, "_kv"):
             m._kv = None
         if hasattr(m, "_graph_cache"):
-            m._graph_cache = {}
+            from .ddim import drop_graph_entries
+            drop_graph_entries(m._graph_cache)
     return sent
 
 

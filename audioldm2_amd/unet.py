@@ -417,7 +417,8 @@ class UNetModel(nn.Module):
     def invalidate_packed(self):
         """Drop every re-laid-out weight copy, cached context projection and captured step graph (call
         after mutating parameters)."""
-        self._graph_cache = {}
+        from .ddim import drop_graph_entries
+        drop_graph_entries(self._graph_cache)   # frees the graphs now, not at some later cyclic collection
         for m in self.modules():
             if hasattr(m, "_pk"):
                 m._pk = None
