@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, (QT == 1 && BX && NP == 2 && !HAS_MASK) ? 4 : 
 #pragma unroll
             for (int r = 0; r < 16; ++r) mkc[r] = mk[r];
         }
-        load_tile(j0 + 32);
+        if (j0 + 32 < Lk) load_tile(j0 + 32);   // (wave uniform; a single-tile launch — cross-attention to 8 or 32 keys — has nothing to prefetch)
         // S^T tile = K Q^T: lane (query l31, half lh) gets its query's scores against keys
         // j0 + (r&3) + 8(r>>2) + 4*lh
         f32x16 st[QT];
@@ -625,9 +625,9 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
                  reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                "aldm_attention_d32: q/k/out must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    // 64 queries per wave (every K / V fragment and its split reused for two query tiles) whenever there are enough keys to
-    // amortise the doubled prologue and the grid still has >= 128 blocks: 1024x1024 self-attention 85.7 us vs 106 (QT = 1),
-    // 256x256 (192 blocks) 14.7 vs 16.5 us on MI355X (profiles/r02_attn_ab.txt)
+    // 64 queries per wave (every K / V fragment and its split reused for two query tiles) whenever the grid still has >= 128
+    // blocks: 1024x1024 self-attention 85.7 us vs 106 (QT = 1), 256x256 (192 blocks) 14.7 vs 16.5 us, 1024x32 cross-attention
+    // 11.2 vs 13.2 us on MI355X (profiles/r02_attn_ab_pipelined.txt; round 1's kernel preferred QT = 1 for short key lists)
     static const int env_qt = [] {
         const char* e = getenv("ALDM_ATTN_QT");  // A/B override: 1 or 2 query tiles per wave
         return e ? atoi(e) : 0;
@@ -636,7 +636,7 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
         const char* e = getenv("ALDM_ATTN_PIPE");
         return e == nullptr || e[0] != '0';
     }();
-    const bool qt2 = env_qt ? env_qt == 2 : (Lk >= 256 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
+    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 64 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
     const int amode = g_attn_mma < 0 ? default_attn_mode() : g_attn_mma;
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
 #define ALDM_ATTN(M_, Q_, X_, P_)                                                                                 \

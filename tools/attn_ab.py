@@ -32,7 +32,7 @@ def timeit(fn, iters=20):
 
 
 g = torch.Generator().manual_seed(0)
-for B, heads, Lq, Lk in [(16, 8, 1024, 1024), (16, 12, 256, 256), (16, 20, 64, 64), (16, 8, 1024, 32), (16, 8, 1024, 40)]:
+for B, heads, Lq, Lk in [(16, 8, 1024, 1024), (16, 12, 256, 256), (16, 20, 64, 64), (16, 8, 1024, 32), (16, 8, 1024, 40), (16, 8, 1024, 8)]:
     qkv = torch.randn(B, Lq, 3 * heads * 32, generator=g).cuda()
     kv = torch.randn(B, Lk, 2 * heads * 32, generator=g).cuda()
     C = heads * 32
