@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import copy
 import importlib
+import math
 import os
 import random
 from typing import Dict, List, Optional
@@ -679,10 +680,20 @@ def normalize_wav(waveform):
     return waveform * 0.5
 
 
+def resample_to_16k(waveform: np.ndarray, sr: int) -> np.ndarray:
+    """tools.py:31: `torchaudio.functional.resample(waveform, orig_freq=sr, new_freq=16000)` — the windowed-sinc polyphase
+    FIR of torchaudio's defaults (restated: audioldm2_amd.clap.sinc_resample_kernel) on the GPU (aldm_resample_sinc)."""
+    from .clap import sinc_resample_kernel
+    k, width, down, up = sinc_resample_kernel(int(sr), 16000)
+    x = torch.as_tensor(np.ascontiguousarray(waveform, dtype=np.float32)).reshape(1, -1).cuda()
+    n_out = int(math.ceil(up * x.shape[1] / down))
+    return ops.resample_sinc(x, k.cuda(), down, up, width, n_out)[0].cpu().numpy()
+
+
 def read_wav_file(source, segment_length, sr=None):
-    """tools.py:28-40.  `source`: a path to a 16 kHz mono PCM/float .wav (read with scipy; the reference
-    uses torchaudio.load + resample, which is not installed here — other rates raise) or a 1-D float
-    array already at 16 kHz."""
+    """tools.py:28-40.  `source`: a path to a mono PCM/float .wav (read with scipy: torchaudio.load is not installed here;
+    first channel of a multi-channel file, like the reference's `[0, ...]`), resampled to 16 kHz like the reference does,
+    or a 1-D float array already at 16 kHz."""
     if isinstance(source, (str, os.PathLike)):
         from scipy.io import wavfile
         sr, data = wavfile.read(source)
@@ -690,9 +701,9 @@ def read_wav_file(source, segment_length, sr=None):
             data = data[:, 0]
         if np.issubdtype(data.dtype, np.integer):
             data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
-        if sr != 16000:
-            raise NotImplementedError("read_wav_file: resampling needs torchaudio (absent); supply 16 kHz audio")
         waveform = data.astype(np.float32)
+        if sr != 16000:
+            waveform = resample_to_16k(waveform, sr)
     else:
         waveform = np.asarray(source, dtype=np.float32).reshape(-1)
     waveform = normalize_wav(waveform)[None, ...]

@@ -294,3 +294,27 @@ def test_generate_batch_reranks_candidates_like_the_reference():
     best = [i + int(torch.argmax(want[i::B0])) * B0 for i in range(B0)]
     assert m.last_best_index == best
     assert np.array_equal(wav[:, 0], cand.numpy()[best])
+
+
+@pytest.mark.gpu
+def test_read_wav_file_resamples_like_the_reference(tmp_path):
+    """utilities/audio/tools.py:28-40: a .wav at another rate is resampled to 16 kHz (torchaudio.functional.resample in the
+    reference; the restated polyphase sinc filter on the GPU here), then normalised / padded / scaled like the reference."""
+    from scipy.io import wavfile
+    from audioldm2_amd.pipeline import normalize_wav, pad_wav, read_wav_file
+    sr = 44100
+    t = np.arange(int(1.7 * sr)) / sr
+    x = (0.4 * np.sin(2 * np.pi * 440.0 * t) + 0.2 * np.sin(2 * np.pi * 3000.0 * t + 0.5)).astype(np.float32)
+    path = str(tmp_path / "tone44k.wav")
+    wavfile.write(path, sr, x)
+    got = read_wav_file(path, 163840)
+    ref16 = oh.resample(torch.from_numpy(x)[None], sr, 16000)[0].numpy()
+    want = pad_wav(normalize_wav(ref16)[None, ...], 163840)
+    want = 0.5 * want / np.max(np.abs(want))
+    assert got.shape == want.shape == (1, 163840)
+    assert np.abs(got - want).max() < 2e-6
+    # and the 16 kHz signal really is the 440 Hz + 3 kHz pair (the filter kept both, at the new rate)
+    n = ref16.shape[0]
+    t16 = np.arange(n) / 16000.0
+    ideal = 0.4 * np.sin(2 * np.pi * 440.0 * t16) + 0.2 * np.sin(2 * np.pi * 3000.0 * t16 + 0.5)
+    assert np.abs(ref16[400:-400] - ideal[400:-400]).max() < 3e-3
