@@ -9,12 +9,17 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audioldm2_amd import ops  # noqa: E402
 from audioldm2_amd.unet import UNetModel  # noqa: E402
-from oracle import cases  # noqa: E402
+from audioldm2_amd.pipeline import default_audioldm_config  # noqa: E402
 
-cfg = cases.UNET_FULL
+cfg = default_audioldm_config("audioldm2-full")["model"]["params"]["unet_config"]["params"]
 torch.manual_seed(0)
 m = UNetModel(**cfg).cuda().eval()
-x, t, ctxs, masks, _ = cases.unet_inputs(cfg, 16, 256, 16, 32, seed=4)
+g = torch.Generator().manual_seed(4)
+x = torch.randn(16, 8, 256, 16, generator=g)
+t = torch.tensor([(37 * i) % 1000 + 1 for i in range(16)])
+ctxs = [torch.randn(16, 8, 768, generator=g), torch.randn(16, 32, 1024, generator=g)]
+masks = [torch.ones(16, 8), torch.ones(16, 32)]
+masks[1][1::2, -10:] = 0
 xg, tg = x.cuda(), t.cuda()
 cg, mg = [c.cuda() for c in ctxs], [k.cuda() for k in masks]
 for mode in ("f32", "bf16x6", "f32", "bf16x6"):
