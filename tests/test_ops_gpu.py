@@ -501,6 +501,9 @@ def ref_attention(q, k, v, heads, mask=None):
     (2, 8, 1024, 8, True),       # cross attention to 8 AudioMAE tokens
     (2, 12, 256, 77, True),      # ragged Lk, partial mask
     (2, 4, 100, 33, True),       # ragged Lq and Lk
+    (2, 4, 100, 64, True),       # ragged Lq, full key tiles: the software-pipelined kernel with clamped query rows
+    (2, 4, 70, 96, False),       # three key tiles, a second (partial) wave of queries
+    (16, 8, 64, 32, True),       # 64 queries per wave on a 64-query sample (three of the block's four waves exit)
     (1, 2, 40, 1, False),        # single key (uncond T5 token)
 ])
 def test_attention_d32(ops, B, heads, Lq, Lk, masked):
