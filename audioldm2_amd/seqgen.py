@@ -1,6 +1,6 @@
-"""AudioMAE-token sequence generator on the MI355X — EXPERIMENTAL: written after round 1's GPU
-budget was spent; its host logic is verified on the CPU against the reference fixtures with the ops replaced by torch
-stand-ins (tests/test_host_logic.py), its first run on hardware is tests/test_seqgen_gpu.py (opt-in: ALDM_EXPERIMENTAL=1).
+"""AudioMAE-token sequence generator on the MI355X.  Host logic verified on the CPU against the
+reference fixtures with the ops replaced by torch stand-ins (tests/test_host_logic.py); the HIP path against the same fixtures
+in tests/test_seqgen_gpu.py.
 
 Mirrors `Sequence2AudioMAE` (audioldm2/audiomae_gen/sequence_input.py): same constructor keywords, same state-dict keys
 (`start_of_sequence_tokens`, `end_of_sequence_tokens`, `input_sequence_embed_linear.{i}`, `model.{wte,wpe,h.{l}.*,ln_f}` with
@@ -9,7 +9,12 @@ GPT-2's `Conv1D` weights stored [in, out]) and the same `generate(batch, cond_di
 The reference re-runs GPT-2 over the whole prefix for every generated token (sequence_input.py:308-323; 512 full forwards
 for the speech model).  Here the prefix is run once and every later position attends to cached keys / values — the same
 function (oracle/seqgen.py: cached == full re-forward), O(n) instead of O(n^2) forwards.  The cache has a fixed length
-(prefix + steps, rounded up to 4): positions that do not exist yet are masked, so every step launches identical shapes.
+(prefix + steps, rounded up to 4): positions that do not exist yet are masked, so every step launches identical shapes —
+and from the third generated token on the step is ONE HIP graph replay: the position lives in a device tensor (embedding
+row, cache slot and key-mask entry are addressed through it, and a captured add advances it), so nothing in the launch
+sequence changes from token to token.  A decode step is ~160 launches of microsecond kernels (M = batch rows): launched from
+Python it costs 2.4 ms per token — 1.2 s for the speech model's 512 tokens, a third of that config's sampling job — replayed
+as a graph it is bound by the kernels (tools/cond_bench.py, profiles/r02_cond_bench.txt).
 All arithmetic goes through the C ABI: `aldm_layernorm`, `aldm_igemm` (projections with fused bias / tanh-GELU /
 residual; Q·K^T as the NT batched product, P·V through `aldm_pack_kn`), `aldm_softmax_rows_masked`, `aldm_axpby`;
 torch only moves data (concatenation, head split / merge copies, cache writes).
@@ -170,7 +175,36 @@ class Sequence2AudioMAE(nn.Module):
             h = ops.linear(m, blk["m_proj"], res=h)
         return ops.layernorm(h, pk["ln_f"][0], pk["ln_f"][1], LN_EPS).view(B, T, N_EMBD)
 
+    # ---- one new position whose index lives on the device (the graph-replayed decode step) ---------------------------
+    def _decode_one(self, tok: torch.Tensor, pos: torch.Tensor, kc: List[torch.Tensor], vc: List[torch.Tensor],
+                    keymask: torch.Tensor) -> torch.Tensor:
+        """Same arithmetic as `_forward_positions(tok, pos, ...)` for T = 1, with every use of the position going through
+        the one-element int64 device tensor `pos`: embedding row by index_select, cache slot by index_copy_, and no causal
+        limit in the softmax (the key mask already excludes every later position: they have not been switched on yet)."""
+        pk = self._packed()
+        B = tok.shape[0]
+        Z, n_tot = B * N_HEAD, keymask.shape[1]
+        wpe = pk["wpe"].index_select(0, pos).expand(B, 1, N_EMBD).contiguous()
+        h = ops.axpby(tok.contiguous(), wpe, 1.0, 1.0).view(B, N_EMBD)
+        for l, blk in enumerate(pk["blocks"]):
+            a = ops.layernorm(h, blk["ln1"][0], blk["ln1"][1], LN_EPS)
+            qkv = ops.linear(a, blk["c_attn"]).view(B, 1, 3, N_HEAD, HEAD_DIM)
+            q = qkv[:, :, 0].permute(0, 2, 1, 3).reshape(Z, 1, HEAD_DIM)
+            kc[l].view(B, N_HEAD, n_tot, HEAD_DIM).index_copy_(2, pos, qkv[:, :, 1].permute(0, 2, 1, 3))
+            vc[l].view(B, N_HEAD, n_tot, HEAD_DIM).index_copy_(2, pos, qkv[:, :, 2].permute(0, 2, 1, 3))
+            s = ops.gemm_nt(q, kc[l], alpha=1.0 / math.sqrt(HEAD_DIM))
+            p = ops.softmax_rows_masked(s.view(B, N_HEAD, 1, n_tot), keymask, n_tot)
+            o = ops.gemm_packed_batched(p.view(Z, 1, n_tot), ops.pack_kn(vc[l]), n_tot, HEAD_DIM)
+            o = o.view(B, N_HEAD, 1, HEAD_DIM).permute(0, 2, 1, 3).reshape(B, N_EMBD)
+            h = ops.linear(o, blk["c_proj"], res=h)
+            m = ops.layernorm(h, blk["ln2"][0], blk["ln2"][1], LN_EPS)
+            m = ops.linear(m, blk["c_fc"], act=ACT_GELU_TANH)
+            h = ops.linear(m, blk["m_proj"], res=h)
+        return ops.layernorm(h, pk["ln_f"][0], pk["ln_f"][1], LN_EPS).view(B, 1, N_EMBD)
+
     # ---- sequence_input.py:294-325 -------------------------------------------------------------------------------
+    GRAPH_MIN_STEPS = 16  # shorter generations (the 8-token text-to-audio configs) are not worth a capture
+
     @torch.no_grad()
     def generate(self, batch, cond_dict: Optional[dict] = None, no_grad: bool = False):
         if cond_dict is None:
@@ -184,14 +218,38 @@ class Sequence2AudioMAE(nn.Module):
         keymask = torch.zeros((B, n_tot), device=dev)
         keymask[:, :P] = mask
         out = self._forward_positions(x, 0, kc, vc, keymask)
-        tok, toks = out[:, -1:, :].contiguous(), []
-        for t in range(steps):
-            toks.append(tok)
-            if t + 1 == steps:
-                break
-            keymask[:, P + t] = 1.0  # the token joins the sequence (its own key is visible to it)
-            tok = self._forward_positions(tok, P + t, kc, vc, keymask)
-        return torch.cat(toks, dim=1), cond_dict
+        tok = out[:, -1:, :].contiguous()
+        if steps < self.GRAPH_MIN_STEPS:
+            toks = []
+            for t in range(steps):
+                toks.append(tok)
+                if t + 1 == steps:
+                    break
+                keymask[:, P + t] = 1.0  # the token joins the sequence (its own key is visible to it)
+                tok = self._forward_positions(tok, P + t, kc, vc, keymask)
+            return torch.cat(toks, dim=1), cond_dict
+        # long generation (the speech model: 512 tokens): the decode step reads / advances device-side state only and is
+        # replayed as one HIP graph (eager the first time, captured the second: ddim.GraphStepper)
+        from .ddim import GraphStepper
+        toks = torch.empty((B, steps, N_EMBD), device=dev)
+        toks[:, 0:1] = tok
+        st = {"tok": tok.clone(), "pos": torch.full((1,), P, device=dev, dtype=torch.long),
+              "slot": torch.ones((1,), device=dev, dtype=torch.long)}
+
+        def step(e=st):
+            keymask.index_fill_(1, e["pos"], 1.0)        # the token joins the sequence (its own key is visible to it)
+            new = self._decode_one(e["tok"], e["pos"], kc, vc, keymask)
+            e["tok"].copy_(new)
+            toks.index_copy_(1, e["slot"], new)
+            e["pos"] += 1
+            e["slot"] += 1
+        import os
+        run = GraphStepper(step, use_graph=x.is_cuda and os.environ.get("ALDM_NO_GRAPH", "0") != "1")
+        for _ in range(steps - 1):
+            run()
+        run.fn = None          # break the closure cycle: the graph and its pool go with this call, not with a later collection
+        run.graph = None
+        return toks, cond_dict
 
     # ---- conditioning through the sub-modules (sequence_input.py:327-370, 385-403) ---------------------------------
     def get_input(self, batch) -> dict:
