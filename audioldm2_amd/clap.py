@@ -39,6 +39,10 @@ from .stft import STFT, mel_filterbank
 ROBERTA_BASE = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                     max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1)
 JOINT_DIM = 512
+# Where the packed weights and every activation live.  The product has one answer; tests/test_host_logic.py points this at
+# the CPU together with torch stand-ins for `ops` to check the host logic (window indices, bias assembly, gathers) on a
+# GPU-less box — the real ops raise on CPU tensors.
+_DEV = torch.device("cuda")
 # clap/open_clip/model_configs/HTSAT-base.json + htsat.py:1224-1236 ("base")
 AUDIO_CFG = dict(sample_rate=48000, window_size=1024, hop_size=480, mel_bins=64, fmin=50, fmax=14000, clip_samples=480000,
                  class_num=527)
@@ -244,7 +248,7 @@ class HTSAT(nn.Module):
     def _prepare(self):
         if self._pk is not None:
             return self._pk
-        f = lambda t: t.detach().float().cuda().contiguous()
+        f = lambda t: t.detach().float().to(_DEV).contiguous()
         h, a = self.hcfg, self.acfg
         F = a["window_size"] // 2 + 1
         ldm = (F + 3) // 4 * 4
@@ -396,7 +400,7 @@ class CLAPTextModel(nn.Module):
 
     def _prepare(self):
         if self._pk is None:
-            f = lambda t: t.detach().float().cuda().contiguous()
+            f = lambda t: t.detach().float().to(_DEV).contiguous()
             tb = self.text_branch
             layers = []
             for L in tb.encoder.layer:
@@ -542,14 +546,14 @@ class CLAPAudioEmbeddingClassifierFreev2(nn.Module):
         if self.unconditional_token is None:
             raise RuntimeError("call build_unconditional_emb(tokens_of_empty_prompt) first (the reference does it lazily "
                                "through its tokenizer, encoders/modules.py:680-681)")
-        w = torch.as_tensor(batch).to("cuda").float()
+        w = torch.as_tensor(batch).to(_DEV).float()
         if w.dim() == 3:
             w = w.squeeze(1)
         w = w.contiguous()
         if self.sampling_rate != 48000:
             if self._resampler is None:
                 k, width, down, up = sinc_resample_kernel(self.sampling_rate, 48000)
-                self._resampler = (k.cuda(), width, down, up)
+                self._resampler = (k.to(_DEV), width, down, up)
             k, width, down, up = self._resampler
             w = ops.resample_sinc(w, k, down, up, width, int(math.ceil(up * w.shape[1] / down)))
         w = w[:, :AUDIO_CFG["clip_samples"]].contiguous()

@@ -20,6 +20,9 @@ import torch.nn as nn
 
 from . import ops
 
+# device of the packed weights and activations; tests/test_host_logic.py points it at the CPU next to torch stand-ins for `ops`
+_DEV = torch.device("cuda")
+
 
 class _LayerNorm(nn.Module):
     """attentions.py:11-23 (parameters named gamma / beta)."""
@@ -96,7 +99,7 @@ class PhonemeEncoder(nn.Module):
 
     def _prepare(self):
         if self._pk is None:
-            f = lambda t: t.detach().float().cuda().contiguous()
+            f = lambda t: t.detach().float().to(_DEV).contiguous()
             te = self.text_encoder
             enc = te.encoder
             layers = []

@@ -23,6 +23,9 @@ import torch.nn as nn
 
 from . import ops
 
+# device of the packed weights and activations; tests/test_host_logic.py points it at the CPU next to torch stand-ins for `ops`
+_DEV = torch.device("cuda")
+
 FLAN_T5_LARGE = dict(vocab_size=32128, d_model=1024, d_kv=64, d_ff=2816, num_layers=24, num_heads=16,
                      relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
 
@@ -98,7 +101,7 @@ class T5EncoderModel(nn.Module):
 
     def _prepare(self):
         if self._pk is None:
-            f = lambda t: t.detach().float().cuda().contiguous()
+            f = lambda t: t.detach().float().to(_DEV).contiguous()
             layers = []
             for b in self.encoder.block:
                 sa, ff = b.layer[0].SelfAttention, b.layer[1].DenseReluDense

@@ -268,3 +268,181 @@ def test_sequence_generator_host_logic_matches_reference_fixture(monkeypatch, fi
     want = torch.from_numpy(np.load(os.path.join(GOLD, fixture + ".npz"))["out"])
     assert out.shape == want.shape
     assert float((out - want).abs().max() / want.abs().max()) < 1e-5
+
+
+def _torch_ops_stand_in_clap():
+    """Torch (CPU) stand-ins for the ops audioldm2_amd/clap.py calls (both towers) — TEST ONLY, like `_torch_ops_stand_in`:
+    what is checked is the module's own logic (window / shift / merge index tables, the bias + shift-mask assembly, head
+    split and merge, the log-mel and BatchNorm folding, the draw order of the unconditional replacement), against the
+    fixtures generated with the REAL reference classes."""
+    import math
+    import types
+    import torch.nn.functional as F
+    from audioldm2_amd.lib import ACT_GELU, ACT_LOGCLAMP, ACT_LRELU, ACT_TANH
+    base = _torch_ops_stand_in()
+
+    def linear(x, pw, act=0, res=None, act_slope=0.0):
+        y = F.linear(x, pw.w, pw.b)
+        if act == ACT_LOGCLAMP:
+            y = torch.log(torch.clamp(y, min=act_slope))
+        elif act == ACT_GELU:
+            y = F.gelu(y)
+        elif act == ACT_LRELU:
+            y = F.leaky_relu(y, act_slope)
+        elif act == ACT_TANH:
+            y = torch.tanh(y)
+        else:
+            assert act == 0, act
+        return y if res is None else y + res
+
+    def reflect_pad_1d(x, pad):
+        y = F.pad(x[:, None], (pad, pad), mode="reflect")[:, 0]
+        return F.pad(y, (0, (-y.shape[1]) % 4))
+
+    def frames_gemm(sig, frames, hop, pw):
+        return sig.unfold(1, pw.w.shape[1], hop)[:, :frames] @ pw.w.t()
+
+    def power_spec(spec, Fq, ld_out):
+        out = torch.zeros(spec.shape[0], ld_out)
+        out[:, :Fq] = spec[:, :Fq] ** 2 + spec[:, Fq:2 * Fq] ** 2
+        return out
+
+    def bicubic_patchify(x, S, p):
+        B, T, Fm = x.shape
+        ratio = S // Fm
+        img = x[:, None]
+        if T < S * ratio:
+            img = F.interpolate(img, (S * ratio, Fm), mode="bicubic", align_corners=True)
+        img = img.permute(0, 1, 3, 2).reshape(B, 1, Fm, ratio, S).permute(0, 1, 3, 2, 4).reshape(B, 1, S, S)
+        return F.unfold(img, kernel_size=p, stride=p).transpose(1, 2).contiguous()
+
+    def softmax_rows_bias(x, bias, keymask, scale=1.0):
+        s = x * scale + bias[None]
+        return torch.where(keymask[:, None, None, :] != 0, s, torch.full([], float("-inf"))).softmax(-1)
+
+    def resample_sinc(x, k, down, up, width, out_len):
+        y = F.conv1d(F.pad(x[:, None], (width, width + down)), k[:, None], stride=down)
+        return y.transpose(1, 2).reshape(x.shape[0], -1)[:, :out_len].contiguous()
+
+    def rowscale_add(x, s, res=None, divide=False):
+        y = x / torch.clamp(s, min=1e-12)[:, None] if divide else x * s[:, None]
+        return y if res is None else y + res
+
+    return types.SimpleNamespace(
+        **{**vars(base), "linear": linear, "reflect_pad_1d": reflect_pad_1d, "frames_gemm": frames_gemm,
+           "power_spec": power_spec, "col_affine": lambda x, sc, sh: x * sc + sh, "bicubic_patchify": bicubic_patchify,
+           "softmax_rows_bias": softmax_rows_bias, "token_mean": lambda x: x.mean(1),
+           "row_l2norm": lambda x, Fq: x[:, :Fq].norm(dim=-1), "rowscale_add": rowscale_add, "resample_sinc": resample_sinc,
+           "row_cosine": lambda a, b, eps=1e-8: F.cosine_similarity(a, b, dim=-1, eps=eps),
+           "ACT_GELU": ACT_GELU, "ACT_LOGCLAMP": ACT_LOGCLAMP, "ACT_LRELU": ACT_LRELU, "ACT_TANH": ACT_TANH})
+
+
+def test_clap_towers_host_logic_matches_reference_fixtures(monkeypatch):
+    """audioldm2_amd.clap, audio AND text mode, with the device ops replaced by torch stand-ins on the CPU: the HTSAT forward
+    (front end, window partition / cyclic shift / patch merging as row gathers, relative-position bias + shift mask,
+    pooling, projection) reproduces the fixture generated with the REAL `HTSAT_Swin_Transformer`, the RoBERTa tower the
+    transformers fixture, and `cos_similarity` draws the unconditional replacements in the reference's order."""
+    from audioldm2_amd import clap
+    from oracle import cases, weights
+    monkeypatch.setattr(clap, "ops", _torch_ops_stand_in_clap())
+    monkeypatch.setattr(clap, "_DEV", torch.device("cpu"))
+    with open(os.path.join(GOLD, "htsat_keys.json")) as f:
+        ashapes = {k: tuple(v) for k, v in json.load(f).items()}
+    with open(os.path.join(GOLD, "clap_text_keys.json")) as f:
+        tshapes = {k: tuple(v) for k, v in json.load(f).items()}
+    m = clap.CLAPAudioEmbeddingClassifierFreev2(embed_mode="audio", unconditional_prob=0.0, sampling_rate=16000,
+                                                config=cases.clap_text_test_config(), audio_config=cases.htsat_test_config())
+    sd = {**cases.htsat_state_dict(ashapes), **weights.make_state_dict(tshapes, seed=0)}
+    missing = m.model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    ids, mask = cases.clap_text_tokens()
+    m.build_unconditional_emb({"input_ids": ids[2:3].repeat(2, 1), "attention_mask": mask[2:3].repeat(2, 1)})
+    ga = np.load(os.path.join(GOLD, "htsat_base2222_b2.npz"))
+    gt = np.load(os.path.join(GOLD, "clap_text_base2_b3.npz"))
+    wav = cases.clap_waveform(2)
+    out = m(wav[:, None])                                   # forward(), "audio" mode
+    want = torch.from_numpy(ga["emb"])
+    assert tuple(out.shape) == (2, 1, 512)
+    assert float((out[:, 0] - want).abs().max() / want.abs().max()) < 2e-5
+    m.embed_mode = "text"
+    temb = m.encode_tokens(ids, mask)
+    assert float((temb[:, 0] - torch.from_numpy(gt["emb"])).abs().max()) < 2e-5
+    m.embed_mode = "audio"
+    # cos_similarity: audio draws first, then text (encoders/modules.py:639-653); rows replaced by the unconditional token
+    m.unconditional_prob = 0.5
+    torch.manual_seed(3)
+    sim = m.cos_similarity(wav, {"input_ids": ids[:2], "attention_mask": mask[:2]})
+    torch.manual_seed(3)
+    draws = [float(torch.rand(1)) < 0.5 for _ in range(4)]
+    u = m.unconditional_token[0]
+    a2 = torch.stack([u if draws[i] else want[i] for i in range(2)])
+    t2 = torch.stack([u if draws[2 + i] else torch.from_numpy(gt["emb"])[i] for i in range(2)])
+    ref = torch.nn.functional.cosine_similarity(a2, t2, dim=-1)
+    assert torch.allclose(sim, ref, atol=5e-5) and m.embed_mode == "audio"
+
+
+def test_t5_and_phoneme_host_logic_match_reference_fixtures(monkeypatch):
+    """audioldm2_amd.t5 / audioldm2_amd.phoneme with the device ops replaced by torch stand-ins on the CPU: the bucketed
+    relative-position bias, key padding to a multiple of 4, the fused q/k/v and gated-FF weight layouts (T5); masks, the
+    scaled embedding table, the FFN's masked convolutions and the positional embedding (phoneme encoder) reproduce the
+    fixtures generated with the REAL reference classes."""
+    import math
+    import types
+    import torch.nn.functional as F
+    from audioldm2_amd import phoneme as pph
+    from audioldm2_amd import t5 as pt5
+    from audioldm2_amd.lib import ACT_GELU_TANH, ACT_LRELU
+    from oracle import cases
+    from oracle import phoneme as oph
+    base = _torch_ops_stand_in_clap()
+
+    def linear_geglu(x, pw, split_out=None, gate_act=0):
+        y = F.linear(x, pw.w, pw.b)
+        inner = y.shape[-1] // 2
+        gate = y[..., inner:]
+        assert gate_act == ACT_GELU_TANH
+        return y[..., :inner] * (0.5 * gate * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (gate + 0.044715 * gate ** 3))))
+
+    def conv(x, pw, pad=(0, 0), act=0, act_slope=0.0):   # the phoneme FFN: [B, 1, T, C] * [N, C, k] along T
+        y = F.conv1d(x[:, 0].transpose(1, 2), pw.w, pw.b, padding=pad[1]).transpose(1, 2)
+        if act == ACT_LRELU:
+            y = F.leaky_relu(y, act_slope)
+        return y[:, None]
+
+    def rel_attention(q, k, v, heads, ek, ev, mask):
+        B, T, C = q.shape
+        hs = lambda t: t.reshape(B, T, heads, C // heads).transpose(1, 2)
+        return oph.rel_attention(hs(q), hs(k), hs(v), ek[None], ev[None], mask).transpose(1, 2).reshape(B, T, C)
+
+    def rowscale_add(x, s, res=None, divide=False):
+        y = x * s.reshape(*x.shape[:-1], 1)
+        return y if res is None else y + res
+
+    ops_t = types.SimpleNamespace(**{**vars(base), "pack_geglu": base.pack_conv, "linear_geglu": linear_geglu,
+                                     "rmsnorm": lambda x, w, eps=1e-6: w * x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps),
+                                     "conv": conv, "rel_attention": rel_attention, "rowscale_add": rowscale_add,
+                                     "ACT_GELU_TANH": ACT_GELU_TANH})
+    cpu = torch.device("cpu")
+    # ---- FLAN-T5
+    monkeypatch.setattr(pt5, "ops", ops_t)
+    monkeypatch.setattr(pt5, "_DEV", cpu)
+    with open(os.path.join(GOLD, "t5_keys.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    m = pt5.FlanT5HiddenState(config=cases.t5_test_config())
+    m.model.load_state_dict(cases.t5_state_dict(shapes), strict=True)
+    g = np.load(os.path.join(GOLD, "t5_large3_b3.npz"))
+    ids, mask = cases.t5_tokens()
+    h, am = m.encode_tokens(ids, mask)
+    want = torch.from_numpy(g["hidden"])
+    assert float((h - want).abs().max() / want.abs().max()) < 1e-5 and np.array_equal(am.numpy(), g["mask"])
+    # ---- VITS phoneme encoder
+    monkeypatch.setattr(pph, "ops", ops_t)
+    monkeypatch.setattr(pph, "_DEV", cpu)
+    with open(os.path.join(GOLD, "phoneme_keys.json")) as f:
+        pshapes = {k: tuple(v) for k, v in json.load(f).items()}
+    pe = pph.PhonemeEncoder(**cases.PHONEME)
+    pe.load_state_dict(cases.phoneme_state_dict(pshapes), strict=True)
+    gp = np.load(os.path.join(GOLD, "phoneme_speech_b4.npz"))
+    emb, pm = pe(cases.phoneme_input())
+    wantp = torch.from_numpy(gp["emb"])
+    assert float((emb - wantp).abs().max() / wantp.abs().max()) < 1e-5 and np.array_equal(pm.numpy(), gp["mask"])
