@@ -189,7 +189,8 @@ class _NoiseFeed:
 def host_drawer(shape, noise_shard=None):
     """draw() -> one `torch.randn(shape)` from the host default generator, in the reference's order; draw.into(dst) writes
     it into `dst`.  noise_shard = (global_batch, row_offset): a prompt-sharded run draws the GLOBAL batch like the
-    single-process reference and keeps rows [offset, offset + shape[0]) (dist.py)."""
+    single-process reference and keeps rows [offset, offset + shape[0]) (dist.py); with several candidates per prompt
+    the second element is the index tensor of the rank's rows (dist.candidate_rows) instead of an offset."""
     shape = tuple(shape)
     if noise_shard is None:
         def draw():
@@ -200,12 +201,17 @@ def host_drawer(shape, noise_shard=None):
     else:
         gB, off = noise_shard
         gshape = (gB,) + shape[1:]
+        if torch.is_tensor(off):
+            assert off.numel() == shape[0]
+            pick = lambda t: t.index_select(0, off)
+        else:
+            pick = lambda t: t[off:off + shape[0]]
 
         def draw():
-            return torch.randn(gshape)[off:off + shape[0]].contiguous()
+            return pick(torch.randn(gshape)).contiguous()
 
         def into(dst):
-            dst.numpy()[...] = torch.randn(gshape)[off:off + shape[0]].numpy()
+            dst.numpy()[...] = pick(torch.randn(gshape)).numpy()
     draw.into = into
     return draw
 

@@ -47,6 +47,16 @@ def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def candidate_rows(n_prompts: int, n_gen: int, rank: int, world: int) -> torch.Tensor:
+    """Rows of the GLOBAL candidate-major batch (row = candidate * n_prompts + prompt, the layout `torch.cat([z] * n_gen)` of
+    ddpm.py:1515-1530 gives) that belong to `rank` when PROMPTS are sharded contiguously: all n_gen candidates of the rank's
+    prompts, again candidate-major — so the re-ranking of ddpm.py:1559-1564 (`best = i + argmax * B`) runs locally with B =
+    the rank's prompt count."""
+    lo, hi = shard_range(n_prompts, rank, world)
+    p = torch.arange(lo, hi)
+    return (torch.arange(n_gen)[:, None] * n_prompts + p[None, :]).reshape(-1)
+
+
 def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_bytes: int = 512 << 20,
                       even_alone: bool = False) -> int:
     """One-time weight broadcast: tensors are packed into flat buckets (few large collectives instead

@@ -555,24 +555,30 @@ class LatentDiffusion(nn.Module):
             for key, meta in self.cond_stage_model_metadata.items():
                 unconditional_conditioning[key] = self.cond_stage_models[
                     meta["model_idx"]].get_unconditional_condition(batch_size)
-        shard = kwargs.get("shard", None)  # (rank, world): sample only this process's contiguous slice
+        shard = kwargs.get("shard", None)  # (rank, world): sample only this process's contiguous slice of the PROMPTS
         self.noise_shard = None
+        Bp = B0                                  # prompts sampled by this process
         if shard is not None:
-            from .dist import shard_range
-            assert n_gen == 1, "prompt sharding keeps a prompt's candidates together: use n_gen == 1 per shard"
-            lo, hi = shard_range(batch_size, shard[0], shard[1])
+            from .dist import candidate_rows, shard_range
+            lo, hi = shard_range(B0, shard[0], shard[1])
+            Bp = hi - lo
+            # rows of the global candidate-major batch: every candidate of our prompts (a prompt's candidates stay together,
+            # SURVEY §8(e)); with one candidate per prompt this is the contiguous slice [lo, hi)
+            rows = candidate_rows(B0, n_gen, shard[0], shard[1])
 
             def cut(v):
                 if isinstance(v, (list, tuple)):
                     return [cut(e) for e in v]
                 if isinstance(v, dict):
                     return {kk: cut(vv) for kk, vv in v.items()}
-                return v[lo:hi].contiguous()
+                return v[lo:hi].contiguous() if n_gen == 1 else v.index_select(0, rows.to(v.device)).contiguous()
             c = {k: cut(v) for k, v in c.items()}
             if unconditional_conditioning is not None:
                 unconditional_conditioning = {k: cut(v) for k, v in unconditional_conditioning.items()}
-            self.noise_shard = (batch_size, lo)  # noise is drawn for the global batch, rows [lo, hi) kept
-            batch_size = hi - lo
+            text = [text[i] for i in rows.tolist()]
+            # noise is drawn for the global batch, our rows kept
+            self.noise_shard = (batch_size, lo) if n_gen == 1 else (batch_size, rows)
+            batch_size = Bp * n_gen
         try:
             samples, _ = self.sample_log(cond=c, batch_size=batch_size, x_T=x_T, ddim=use_ddim,
                                          ddim_steps=ddim_steps, eta=ddim_eta,
@@ -588,9 +594,9 @@ class LatentDiffusion(nn.Module):
             # ddpm.py:1554-1568: keep, per prompt, the candidate whose CLAP audio embedding is closest to the text's
             similarity = self.clap.cos_similarity(torch.FloatTensor(waveform).squeeze(1), text)
             best = []
-            for i in range(B0):
-                cand = similarity[i::B0]
-                best.append(i + torch.argmax(cand).item() * B0)
+            for i in range(Bp):
+                cand = similarity[i::Bp]
+                best.append(i + torch.argmax(cand).item() * Bp)
             waveform = waveform[best]
             self.last_similarity, self.last_best_index = similarity.detach().cpu(), best
         return waveform

@@ -78,3 +78,44 @@ def test_shard_range_properties():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_candidate_rows_keep_a_prompts_candidates_on_one_rank_and_rerank_like_one_process():
+    """Prompt sharding with n_candidate_gen_per_text > 1: the reference lays the candidates out candidate-major
+    (`torch.cat([z] * n_gen)`, row = candidate * B + prompt) and picks `best = i + argmax(similarity[i::B]) * B`
+    (ddpm.py:1559-1564).  A rank samples every candidate of ITS prompts, draws the global noise and keeps those rows; ranking
+    them locally must choose the very rows a single process would."""
+    from audioldm2_amd.ddim import host_drawer
+    from audioldm2_amd.dist import candidate_rows, shard_range
+    B, n_gen = 7, 3
+    g = torch.Generator().manual_seed(0)
+    sim = torch.rand(B * n_gen, generator=g)                       # one similarity per global row
+    single = [i + int(torch.argmax(sim[i::B])) * B for i in range(B)]
+    for world in (1, 2, 3, 8):
+        seen, chosen = [], []
+        for rank in range(world):
+            rows = candidate_rows(B, n_gen, rank, world)
+            lo, hi = shard_range(B, rank, world)
+            Bp = hi - lo
+            assert rows.numel() == Bp * n_gen
+            assert torch.equal(rows.view(n_gen, Bp) % B, torch.arange(lo, hi).expand(n_gen, Bp))   # our prompts, all candidates
+            assert torch.equal(rows.view(n_gen, Bp) // B, torch.arange(n_gen)[:, None].expand(n_gen, Bp))  # candidate-major
+            seen += rows.tolist()
+            local = sim[rows]
+            best = [j + int(torch.argmax(local[j::Bp])) * Bp for j in range(Bp)] if Bp else []
+            chosen += [int(rows[b]) for b in best]
+            # the noise rows of this rank = those rows of the single-process draw
+            if Bp:
+                torch.manual_seed(5)
+                mine = host_drawer((Bp * n_gen, 2, 3), (B * n_gen, rows))()
+                torch.manual_seed(5)
+                full = torch.randn(B * n_gen, 2, 3)
+                assert torch.equal(mine, full[rows])
+                dst = torch.empty(Bp * n_gen, 2, 3)
+                torch.manual_seed(5)
+                host_drawer((Bp * n_gen, 2, 3), (B * n_gen, rows)).into(dst)
+                assert torch.equal(dst, full[rows])
+        assert sorted(seen) == list(range(B * n_gen))
+        assert chosen == single
+    # one candidate per prompt: the rows are the contiguous slice the n_gen == 1 path has always used
+    assert candidate_rows(7, 1, 1, 2).tolist() == list(range(*shard_range(7, 1, 2)))
