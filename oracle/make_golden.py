@@ -356,30 +356,12 @@ def gen_htsat():
     """§8(f) rank 4: the REAL `HTSAT_Swin_Transformer` (clap/open_clip/htsat.py) at HTSAT-base's geometry with depths (2,2,2,2),
     its two torchlibrosa extractors (absent here) replaced by the restated ones of oracle/htsat.py, + the reference's
     audio_projection head (model.py:563-567): 16 kHz waveforms -> resample -> embedding -> normalised CLAP audio embedding."""
-    import types
     import torch.nn as nn
     import torch.nn.functional as F
     from oracle import htsat as oh
-    refimport.install()
-    import importlib
-    ht = importlib.import_module("audioldm2.clap.open_clip.htsat")
     hc = cases.htsat_test_config()
     ac = dict(oh.AUDIO_CFG)
-    cfg = types.SimpleNamespace(audio_length=1024, clip_samples=ac["clip_samples"], mel_bins=ac["mel_bins"],
-                                sample_rate=ac["sample_rate"], window_size=ac["window_size"], hop_size=ac["hop_size"],
-                                fmin=ac["fmin"], fmax=ac["fmax"], class_num=527, model_type="HTSAT", model_name="base")
-    m = ht.HTSAT_Swin_Transformer(spec_size=256, patch_size=4, patch_stride=(4, 4), num_classes=527, embed_dim=hc["embed_dim"],
-                                  depths=list(hc["depths"]), num_heads=list(hc["num_heads"]), window_size=hc["window_size"],
-                                  config=cfg, enable_fusion=False, fusion_type="None").eval()
-
-    class Spec(nn.Module):   # torchlibrosa.stft.Spectrogram: (B, T) -> (B, 1, frames, freq)
-        def forward(self, x):
-            return oh.power_spectrogram(x, ac["window_size"], ac["hop_size"])[:, None]
-
-    class LogMel(nn.Module):  # torchlibrosa.stft.LogmelFilterBank: (B, 1, frames, freq) -> (B, 1, frames, mel)
-        def forward(self, x):
-            return oh.logmel(x[:, 0], ac)[:, None]
-    m.spectrogram_extractor, m.logmel_extractor = Spec(), LogMel()
+    m = refimport.htsat_swin_transformer(hc, ac)
     proj = nn.Sequential(nn.Linear(8 * hc["embed_dim"], 512), nn.ReLU(), nn.Linear(512, 512)).eval()
     skip = ("relative_position_index", "attn_mask", "num_batches_tracked", "tscam_conv", "head.")
     shapes = {"audio_branch." + k: tuple(v.shape) for k, v in m.state_dict().items() if not any(t in k for t in skip)}

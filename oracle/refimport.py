@@ -182,3 +182,33 @@ def flan_t5_hidden_state(cfg: dict, token_batch):
     finally:
         mod.T5Config, mod.AutoTokenizer = saved
     return m.eval()
+
+
+def htsat_swin_transformer(hcfg: dict, acfg: dict):
+    """The REAL `HTSAT_Swin_Transformer` (audioldm2/clap/open_clip/htsat.py:777) at geometry `hcfg`, in eval mode, with its two
+    torchlibrosa extractors (a package that is neither vendored nor installed) replaced by the restated ones of
+    oracle/htsat.py; everything downstream of the log-mel — bn0, reshape_wav2img, patch embedding, every Swin block, patch
+    merging, pooling — is the reference's own code."""
+    install()
+    import importlib
+    import types
+    import torch.nn as nn
+    from . import htsat as oh
+    ht = importlib.import_module("audioldm2.clap.open_clip.htsat")
+    cfg = types.SimpleNamespace(audio_length=1024, clip_samples=acfg["clip_samples"], mel_bins=acfg["mel_bins"],
+                                sample_rate=acfg["sample_rate"], window_size=acfg["window_size"], hop_size=acfg["hop_size"],
+                                fmin=acfg["fmin"], fmax=acfg["fmax"], class_num=527, model_type="HTSAT", model_name="base")
+    m = ht.HTSAT_Swin_Transformer(spec_size=hcfg["spec_size"], patch_size=hcfg["patch"], patch_stride=(hcfg["patch"],) * 2,
+                                  num_classes=527, embed_dim=hcfg["embed_dim"], depths=list(hcfg["depths"]),
+                                  num_heads=list(hcfg["num_heads"]), window_size=hcfg["window_size"], config=cfg,
+                                  enable_fusion=False, fusion_type="None").eval()
+
+    class Spec(nn.Module):   # torchlibrosa.stft.Spectrogram: (B, T) -> (B, 1, frames, freq)
+        def forward(self, x):
+            return oh.power_spectrogram(x, acfg["window_size"], acfg["hop_size"])[:, None]
+
+    class LogMel(nn.Module):  # torchlibrosa.stft.LogmelFilterBank: (B, 1, frames, freq) -> (B, 1, frames, mel)
+        def forward(self, x):
+            return oh.logmel(x[:, 0], acfg)[:, None]
+    m.spectrogram_extractor, m.logmel_extractor = Spec(), LogMel()
+    return m

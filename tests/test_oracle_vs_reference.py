@@ -90,3 +90,22 @@ def test_sequence_generator_oracle_equals_live_reference():
     x, mask = seqgen.input_sequence_and_mask(sd, cond, cfg["keys"], cfg["steps"])
     assert rel(seqgen.generate_full(sd, x, mask, cfg["steps"]), want) < 1e-5
     assert rel(seqgen.generate_cached(sd, x, mask, cfg["steps"]), want) < 1e-5
+
+
+def test_htsat_oracle_equals_live_reference():
+    """§8(f) rank 4: HTSAT_Swin_Transformer.forward(...)["embedding"] (clap/open_clip/htsat.py:1092-1127) on audio that is not
+    in the committed fixture — other weights, one sample, a 6 s clip (601 frames: the bicubic stretch of reshape_wav2img runs
+    at a different ratio) — with depths (1, 2, 1, 2): a stage that ends on an unshifted block and one with a shifted one."""
+    from oracle import htsat as oh
+    hc = dict(cases.htsat_test_config(), depths=(1, 2, 1, 2))
+    ac = dict(oh.AUDIO_CFG)
+    m = refimport.htsat_swin_transformer(hc, ac)
+    skip = ("relative_position_index", "attn_mask", "num_batches_tracked", "tscam_conv", "head.")
+    shapes = {"audio_branch." + k: tuple(v.shape) for k, v in m.state_dict().items() if not any(t in k for t in skip)}
+    sd = cases.htsat_state_dict(shapes, seed=5)
+    missing = m.load_state_dict({k[len("audio_branch."):]: v for k, v in sd.items()}, strict=False)
+    assert all(any(t in k for t in skip) for k in missing.missing_keys) and not missing.unexpected_keys
+    wav48 = oh.resample(cases.clap_waveform(1, seed=33), 16000, 48000)[:, :288000]
+    with torch.no_grad():
+        want = m({"waveform": wav48}, device="cpu")["embedding"]
+    assert rel(oh.htsat_embedding(sd, wav48, hc, ac), want) < 1e-5
