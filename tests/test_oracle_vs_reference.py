@@ -109,3 +109,39 @@ def test_htsat_oracle_equals_live_reference():
     with torch.no_grad():
         want = m({"waveform": wav48}, device="cpu")["embedding"]
     assert rel(oh.htsat_embedding(sd, wav48, hc, ac), want) < 1e-5
+
+
+def test_phoneme_and_t5_oracles_equal_live_reference():
+    """§8(f) ranks 1 (second half) and 2: the REAL PhonemeEncoder and FlanT5HiddenState on inputs and weights that are not in
+    the committed fixtures."""
+    from oracle import phoneme as oph
+    from oracle import t5 as ot5
+    # VITS phoneme encoder: other weights, other ids / lengths
+    m = refimport.phoneme_encoder(**cases.PHONEME)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = cases.phoneme_state_dict(shapes, seed=4)
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(17)
+    idx = torch.randint(1, cases.PHONEME["vocabs_size"], (3, cases.PHONEME["pad_length"]), generator=g)
+    for b, n in enumerate((310, 57, 1)):
+        idx[b, n:] = cases.PHONEME["pad_token_id"]
+    with torch.no_grad():
+        want, wmask = m(idx)
+    emb, mask = oph.phoneme_encoder_forward(sd, idx, cases.PHONEME["pad_token_id"])
+    assert rel(emb, want) < 1e-5 and torch.equal(mask, wmask)
+    # FLAN-T5 encoder: other weights, other token batch (lengths 9, 17, 2 padded to 17)
+    cfg = cases.t5_test_config()
+    ids = torch.randint(3, cfg["vocab_size"], (3, 17), generator=g)
+    am = torch.zeros(3, 17, dtype=torch.long)
+    for b, n in enumerate((9, 17, 2)):
+        ids[b, n - 1] = 1
+        ids[b, n:] = 0
+        am[b, :n] = 1
+    ref = refimport.flan_t5_hidden_state(cfg, lambda prompt: (ids, am))
+    tshapes = {k: tuple(v.shape) for k, v in ref.model.state_dict().items()}
+    tsd = cases.t5_state_dict(tshapes, seed=6)
+    ref.model.load_state_dict(tsd, strict=True)
+    with torch.no_grad():
+        hs, ram = ref(["x", "y", "z"])
+    h, m2 = ot5.encode_tokens(tsd, cfg, ids, am)
+    assert rel(h, hs) < 1e-5 and torch.equal(m2.float(), ram.float())
