@@ -22,6 +22,9 @@ int igemm_launch_bx_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 gr
 // DMA-fed kernel over pre-split operands (igemm_dma.hip)
 int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_config_ok(int BM, int BN, int nst, int parts);
+// ... and its persistent wave-specialised form (igemm_dma_ws.hip)
+int igemm_launch_dma_ws(int BM, int BN, int nst, int parts, int blocks, hipStream_t st, const IgemmK& p);
+bool igemm_dma_ws_config_ok(int BM, int BN, int nst, int parts);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -215,6 +218,32 @@ static int pre_mode_of(const aldm_igemm_desc& d) {
     return PRE_GENERIC;
 }
 
+// compute units of the current device (the persistent kernels launch one block per CU)
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 256;
+        return cus;
+    }();
+    return n;
+}
+
+// the persistent wave-specialised DMA kernel handles the vector epilogue without ragged tiles, activation, row remap,
+// accumulation or split-K (igemm_dma_ws.h); everything else stays on igemm_dma_kernel
+static bool dma_ws_eligible(const IgemmK& p, int BM, int BN) {
+    const aldm_igemm_desc& d = p.d;
+    const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (d.out_mul > 0 || d.accumulate || d.batch != 1 || d.act != ALDM_ACT_NONE) return false;
+    if (p.M % BM != 0 || d.N % BN != 0 || (d.N & 3) != 0 || (d.ldo & 3) != 0) return false;
+    if (!al16(d.out) || !al16(d.res) || !al16(d.bias) || !al16(d.rowbias) || !al16(d.out_split)) return false;
+    if (d.rowbias && (p.OHW % BM != 0 || (p.rb_ld & 3) != 0)) return false;
+    if (geglu && (BN != 128 || d.res || d.rowbias)) return false;
+    return true;
+}
+
 static bool tile_supported(int BM, int BN) {
     return (BM == 128 && (BN == 128 || BN == 64 || BN == 32)) || (BM == 64 && (BN == 128 || BN == 64));
 }
@@ -300,6 +329,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     const int pre = pre_mode_of(d);
     p.dma = 0;
     p.nst = 0;
+    p.ws = 0;
+    p.ws_blocks = 0;
     if (d.out_split) {
         ALDM_CHECK(d.out_split_c > 0 && d.out_split_c % 32 == 0 && d.out_split_c >= (geglu ? d.N / 2 : d.N) &&
                        d.N % 4 == 0 && d.batch == 1 && (reinterpret_cast<uintptr_t>(d.out_split) & 15) == 0 &&
@@ -340,7 +371,12 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         int splits = 1, nst = 0;
         const int f_bm = g_force_bm ? g_force_bm : d.hint_bm, f_bn = g_force_bm ? g_force_bn : d.hint_bn;
         const int f_sp = g_force_bm ? g_force_splits : d.hint_splits;
-        const int f_st = g_force_bm ? g_force_stages : d.hint_stages;
+        int f_st = g_force_bm ? g_force_stages : d.hint_stages;
+        int ws_nst = 0;   // stages >= 100: the persistent wave-specialised kernel with a ring of (stages - 100)
+        if (f_st >= 100) {
+            ws_nst = f_st - 100;
+            f_st = 0;
+        }
         if (f_bm) {
             BM = f_bm;
             BN = f_bn;
@@ -392,6 +428,22 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         p.pre = pre;
         p.dma = 1;
         p.nst = nst;
+        p.ws = 0;
+        p.ws_blocks = 0;
+        if (ws_nst > 0) {
+            // hinted / forced persistent form; a launch the persistent kernel cannot run (tuned tables are keyed by geometry,
+            // not by epilogue flags) keeps the tile on igemm_dma_kernel with that tile's default ring
+            if (splits == 1 && igemm_dma_ws_config_ok(BM, BN, ws_nst, d.split_parts) && dma_ws_eligible(p, BM, BN)) {
+                const int ntiles = p.tiles_m * p.tiles_n;
+                const int per = cdiv(ntiles, device_cus());
+                p.ws = 1;
+                p.nst = ws_nst;
+                p.ws_blocks = cdiv(ntiles, per);
+            } else {
+                ALDM_CHECK(!g_force_bm, "aldm_igemm: the persistent DMA kernel cannot run this launch (tile %dx%d, %d stages)", BM,
+                           BN, ws_nst);
+            }
+        }
         return 0;
     }
     const bool bx_ok = d.w_split != nullptr && d.split_parts == 3 && d.b_mode == ALDM_B_PACKED && d.stride_w == 0 && d.batch == 1 &&
@@ -512,7 +564,7 @@ extern "C" int aldm_igemm_plan_stages(const aldm_igemm_desc* dd) {
     IgemmK p;
     int BM, BN;
     if (igemm_prepare(dd, p, BM, BN)) return -1;
-    return p.dma ? p.nst : 0;
+    return p.dma ? p.nst + (p.ws ? 100 : 0) : 0;
 }
 
 extern "C" int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* dd) {
@@ -548,7 +600,9 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     // BX: the 128x128 image leaves room for one block per CU, so that tile takes 8 waves for every prologue
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
                     (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
-    if (p.dma) {
+    if (p.dma && p.ws) {
+        rc = igemm_launch_dma_ws(BM, BN, p.nst, d.split_parts, p.ws_blocks, st, p);
+    } else if (p.dma) {
         rc = igemm_launch_dma(BM, BN, p.nst, d.split_parts, grid, st, p);
     } else if (p.bx) {
         switch (pre) {

@@ -23,6 +23,8 @@ struct IgemmK {
     int pre;                   // PRE_* prologue mode of the descriptor
     int dma;                   // 1: DMA-fed kernel over a pre-split A image (d.a_split)
     int nst;                   // DMA kernel: LDS ring depth of the chosen instantiation
+    int ws;                    // 1: the persistent wave-specialised DMA kernel (igemm_dma_ws.h), ws_blocks blocks
+    int ws_blocks;
 };
 
 enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4 };

@@ -320,8 +320,10 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     """The igemm instantiation a descriptor dispatches to, spelled like rocprofv3's kernel names
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
     if d.a_split:
-        return (f"igemm_dma_kernel<{bm}, {bn}, {_l.load().aldm_igemm_plan_stages(C.byref(d))}, {4 if bm == 256 else 2}, "
-                f"{d.split_parts or 3}>")
+        nst = _l.load().aldm_igemm_plan_stages(C.byref(d))
+        if nst >= 100:   # the persistent wave-specialised form (csrc/igemm_dma_ws.h)
+            return f"igemm_dma_ws_kernel<{bm}, {bn}, {nst - 100}, {d.split_parts or 3}>"
+        return f"igemm_dma_kernel<{bm}, {bn}, {nst}, {4 if bm == 256 else 2}, {d.split_parts or 3}>"
     pre = _pre_mode(d)
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     # 8 waves per tile: same rule as csrc/igemm.hip (ALDM_IGEMM_W8 tile mask, default 128x128 GroupNorm prologues)

@@ -130,7 +130,10 @@ typedef struct aldm_igemm_desc {
        grade) instead of the fp32 MFMA.  NULL => fp32 MFMA.                         */
     const void* w_split;
     int32_t hint_mma;      /* tuned table: 1 = fp32 MFMA even when w_split is set, 0 = automatic          */
-    int32_t hint_stages;   /* DMA-fed kernel: LDS ring depth (0 = automatic)                              */
+    int32_t hint_stages;   /* DMA-fed kernel: LDS ring depth (0 = automatic); 100 + depth = the persistent wave-
+                              specialised form (one 512-thread block per CU walks a run of tiles: 4 waves run the K
+                              loops, 4 waves the previous tile's epilogue) when the launch qualifies: no split-K /
+                              activation / row remap / accumulate, whole tiles, 16-byte aligned operands            */
     /* ABI v5: pre-split operands ("split images", see aldm_split_rows).  When a_split is set the A operand is NOT
        gathered from x1/x2 but from the split image of the [B, H, W, C1] input (C1 % 32 == 0, C2 = 0, no prologue:
        normalisation / activation were applied by whoever wrote the image) and both operands go global -> LDS by
@@ -164,7 +167,9 @@ int aldm_igemm_plan_stages(const aldm_igemm_desc* d);
  * aldm_igemm calls on this thread; bm = 0 => automatic.  bm x bn in {128x128,128x64,64x128,64x64,128x32}. */
 void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
 /* ... and the LDS ring depth of the DMA-fed kernel (a_split descriptors): 128x128 {2,3}, 64x128 / 128x64 {2,4},
- * 64x64 {2,3}; 0 = default for the tile.  aldm_igemm_force() resets it to 0.                                  */
+ * 64x64 {2,3}; 0 = default for the tile; 100 + depth = the persistent wave-specialised kernel (64x128 {3,4,5}, 128x64
+ * {3,4}, 64x64 {4,6} on 2-part images; 64x128 / 128x64 {2,3}, 64x64 {3,4} on 3-part images) — a forced launch it cannot
+ * run fails.  aldm_igemm_force() resets it to 0.                                                              */
 void aldm_igemm_force_stages(int stages);
 /* Tuning override (tests / tools): bit mask of the block tiles that run with 8 instead of 4 wavefronts per
  * tile on this thread (1: 128x128, 2: 64x128, 4: 128x64 — GroupNorm-prologue launches; 8: 128x128 launches

@@ -182,3 +182,108 @@ def test_linear_geglu_layernorm_attention_split_chain(ops):
     vh = v.view(2, Lk, heads, 32).transpose(1, 2)
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(2, Lq, heads * 32)
     assert rel_err(o_f, ref) < GEMM_TOL
+
+
+# ---- the persistent wave-specialised form (csrc/igemm_dma_ws.h): aldm_igemm_force_stages(100 + ring depth) -------------
+_WS_TILES = {"bf16x6": [(64, 128, 2), (64, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 3), (64, 64, 4)],
+             "bf16x3": [(64, 128, 3), (64, 128, 4), (64, 128, 5), (128, 64, 3), (128, 64, 4), (64, 64, 4), (64, 64, 6)]}
+_OLD_STAGES = {(64, 128): 4, (128, 64): 4, (64, 64): 3}
+
+
+def _ws_vs_old(ops, bm, bn, st, fn):
+    """fn() under the persistent kernel and under igemm_dma_kernel on the same tile: same K order, same epilogue order ->
+    the results must agree BITWISE."""
+    ops.igemm_force(bm, bn, 1, 0, 100 + st)
+    try:
+        y_ws = fn()
+    finally:
+        ops.igemm_force(0, 0, 0)
+    ops.igemm_force(bm, bn, 1, 0, _OLD_STAGES[(bm, bn)])
+    try:
+        y_old = fn()
+    finally:
+        ops.igemm_force(0, 0, 0)
+    return y_ws, y_old
+
+
+@pytest.mark.parametrize("mode,bm,bn,st", [(m, *t) for m, ts in _WS_TILES.items() for t in ts])
+def test_dma_ws_every_tile(mode, bm, bn, st):
+    """Every instantiation of the persistent kernel: a conv with a timestep row bias, a conv with a residual and both outputs,
+    with MORE tiles than compute units (each block walks several tiles: hand-over, prefetch one tile ahead, ring restart)."""
+    from audioldm2_amd import ops
+    prev = ops.set_mma(mode)
+    try:
+        B, C, N, H, W = 5, 64, 128, 64, 64          # M = 20480 rows = 320 row tiles of 64; every sample a whole number of tiles
+        x = torch.randn(B, C, H, W, generator=g(1))
+        w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+        b = torch.randn(N, generator=g(3))
+        emb = torch.randn(B, 2 * N, generator=g(4))
+        res = torch.randn(B, N, H, W, generator=g(5))
+        pw = ops.pack_conv(w, b)
+        xs = ops.split_rows(cl(x))
+        conv = F.conv2d(x, w, b, padding=1)
+        y_ws, y_old = _ws_vs_old(ops, bm, bn, st, lambda: ops.conv(xs, pw, pad=(1, 1), rowbias=emb.cuda()[:, N:]))
+        assert rel_err(uncl(y_ws), conv + emb[:, N:, None, None]) < GEMM_TOL
+        assert torch.equal(y_ws, y_old)
+        (y_ws, s_ws), (y_old, s_old) = _ws_vs_old(
+            ops, bm, bn, st, lambda: ops.conv(xs, pw, pad=(1, 1), res=cl(res), alpha=0.5, split_out="also"))
+        assert rel_err(uncl(y_ws), 0.5 * (conv + res)) < GEMM_TOL
+        assert torch.equal(y_ws, y_old) and torch.equal(s_ws.data, s_old.data)
+        assert_split_equals(ops, s_ws, y_ws)
+        s_only, _ = _ws_vs_old(ops, bm, bn, st, lambda: ops.conv(xs, pw, pad=(1, 1), res=cl(res), alpha=0.5, split_out="only"))
+        assert torch.equal(s_only.data, s_ws.data)
+    finally:
+        ops.set_mma(prev)
+
+
+@pytest.mark.parametrize("K", [32, 64, 96, 256, 1024])
+@pytest.mark.parametrize("M", [64 * 4, 64 * 700])
+def test_dma_ws_linear_k_edges(ops, K, M):
+    """K = 32 / 64: zero / one in-loop barrier per tile (the two roles must still agree on the barrier sequence); K shorter
+    than the ring; M = 256 rows: fewer tiles than compute units (one tile per block, some blocks absent)."""
+    N = 256
+    x = torch.randn(1, M, K, generator=g(1))
+    w = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3))
+    res = torch.randn(1, M, N, generator=g(4))
+    pw = ops.pack_conv(w, b)
+    xs = ops.split_rows(x.cuda())
+    ref = xs.float().double().cpu() @ w.double().t() + b.double() + res.double()
+    for bm, bn, st in _WS_TILES["bf16x3" if ops.split_parts() == 2 else "bf16x6"][::2]:
+        y_ws, y_old = _ws_vs_old(ops, bm, bn, st, lambda: ops.linear(xs, pw, res=res.cuda()))
+        assert rel_err(y_ws, ref) < GEMM_TOL, (bm, bn, st)
+        assert torch.equal(y_ws, y_old), (bm, bn, st)
+
+
+def test_dma_ws_geglu(ops):
+    """The GEGLU epilogue of the persistent kernel (128-column tiles), split-image and fp32 outputs."""
+    M, C = 64 * 300, 128
+    x = torch.randn(1, M, C, generator=g(1))
+    w1 = torch.randn(8 * C, C, generator=g(4)) / math.sqrt(C)
+    b1 = torch.randn(8 * C, generator=g(5))
+    pw = ops.pack_geglu(w1, b1)
+    xs = ops.split_rows(x.cuda())
+    h = xs.float().double().cpu() @ w1.double().t() + b1.double()
+    a, gate = h.chunk(2, -1)
+    ref = a * F.gelu(gate)
+    for bm, bn, st in [t for t in _WS_TILES["bf16x3" if ops.split_parts() == 2 else "bf16x6"] if t[1] == 128]:
+        (y_ws, s_ws), (y_old, s_old) = _ws_vs_old(ops, bm, bn, st, lambda: ops.linear_geglu(xs, pw, split_out="also"))
+        assert rel_err(y_ws, ref) < GEMM_TOL
+        assert torch.equal(y_ws, y_old) and torch.equal(s_ws.data, s_old.data)
+
+
+def test_dma_ws_falls_back_when_not_eligible(ops):
+    """A forced persistent launch the kernel cannot run (ragged M) fails loudly; a HINTED one (tuned tables are keyed by
+    geometry only) quietly stays on igemm_dma_kernel."""
+    M, K, N = 100, 64, 128
+    x = torch.randn(1, M, K, generator=g(1))
+    w = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    pw = ops.pack_conv(w, None)
+    xs = ops.split_rows(x.cuda())
+    st = 100 + (4 if ops.split_parts() == 2 else 3)
+    ops.igemm_force(64, 128, 1, 0, st)
+    try:
+        with pytest.raises(RuntimeError):
+            ops.linear(xs, pw)
+    finally:
+        ops.igemm_force(0, 0, 0)
