@@ -499,6 +499,11 @@ class CLAPAudioEmbeddingClassifierFreev2(nn.Module):
         for p in self.model.parameters():
             p.requires_grad = False
         self.unconditional_token = None
+        # (global_rows, local_rows) while a prompt-sharded job re-ranks: the reference draws one uniform per row of the GLOBAL
+        # candidate batch (audio pass, then text pass); a shard must consume the same draws and keep its rows' decisions
+        self.decision_shard = None
+        self.weights_loaded = False   # set by load_state_dict: a randomly initialised re-ranker must not rank silently
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "weights_loaded", True))
         self.eval()
 
     def tokenizer(self, text):
@@ -534,9 +539,17 @@ class CLAPAudioEmbeddingClassifierFreev2(nn.Module):
     def _draw_unconditional(self, embed):
         """encoders/modules.py:728-735 (both modes; note ddpm.py:114-120 builds the re-ranker with the default probability 0.1)"""
         embed = embed.unsqueeze(1)
-        for i in range(embed.size(0)):
-            if self.make_decision(self.unconditional_prob):
-                embed[i] = self.unconditional_token
+        if self.decision_shard is None:
+            for i in range(embed.size(0)):
+                if self.make_decision(self.unconditional_prob):
+                    embed[i] = self.unconditional_token
+        else:   # sharded: the global batch's draws, this rank's rows
+            g_rows, rows = self.decision_shard
+            assert len(rows) == embed.size(0), (len(rows), embed.size(0))
+            decisions = [self.make_decision(self.unconditional_prob) for _ in range(g_rows)]
+            for i, r in enumerate(rows):
+                if decisions[r]:
+                    embed[i] = self.unconditional_token
         return embed.detach()
 
     def encode_audio(self, batch):

@@ -25,6 +25,10 @@ bool igemm_dma_config_ok(int BM, int BN, int nst, int parts);
 // ... and its persistent wave-specialised form (igemm_dma_ws.hip)
 int igemm_launch_dma_ws(int BM, int BN, int nst, int parts, int blocks, hipStream_t st, const IgemmK& p);
 bool igemm_dma_ws_config_ok(int BM, int BN, int nst, int parts);
+int igemm_dma_ws_blocks_per_cu(int BM, int BN, int nst, int parts);
+// ... and its loader-wave form (igemm_dma_lw.hip): same grid, twice the waves per block
+int igemm_launch_dma_lw(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
+bool igemm_dma_lw_config_ok(int BM, int BN, int nst, int parts);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -372,8 +376,12 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         const int f_bm = g_force_bm ? g_force_bm : d.hint_bm, f_bn = g_force_bm ? g_force_bn : d.hint_bn;
         const int f_sp = g_force_bm ? g_force_splits : d.hint_splits;
         int f_st = g_force_bm ? g_force_stages : d.hint_stages;
-        int ws_nst = 0;   // stages >= 100: the persistent wave-specialised kernel with a ring of (stages - 100)
-        if (f_st >= 100) {
+        int ws_nst = 0;   // stages in [100, 200): the persistent wave-specialised kernel with a ring of (stages - 100)
+        int lw_nst = 0;   // stages >= 200: igemm_dma_kernel with loader waves, ring of (stages - 200)
+        if (f_st >= 200) {
+            lw_nst = f_st - 200;
+            f_st = 0;
+        } else if (f_st >= 100) {
             ws_nst = f_st - 100;
             f_st = 0;
         }
@@ -430,12 +438,17 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         p.nst = nst;
         p.ws = 0;
         p.ws_blocks = 0;
+        if (lw_nst > 0) {
+            ALDM_CHECK(igemm_dma_lw_config_ok(BM, BN, lw_nst, d.split_parts), "aldm_igemm: no loader-wave DMA kernel for tile %dx%d, %d stages", BM, BN, lw_nst);
+            p.ws = 2;
+            p.nst = lw_nst;
+        }
         if (ws_nst > 0) {
             // hinted / forced persistent form; a launch the persistent kernel cannot run (tuned tables are keyed by geometry,
             // not by epilogue flags) keeps the tile on igemm_dma_kernel with that tile's default ring
             if (splits == 1 && igemm_dma_ws_config_ok(BM, BN, ws_nst, d.split_parts) && dma_ws_eligible(p, BM, BN)) {
                 const int ntiles = p.tiles_m * p.tiles_n;
-                const int per = cdiv(ntiles, device_cus());
+                const int per = cdiv(ntiles, device_cus() * igemm_dma_ws_blocks_per_cu(BM, BN, ws_nst, d.split_parts));
                 p.ws = 1;
                 p.nst = ws_nst;
                 p.ws_blocks = cdiv(ntiles, per);
@@ -564,7 +577,7 @@ extern "C" int aldm_igemm_plan_stages(const aldm_igemm_desc* dd) {
     IgemmK p;
     int BM, BN;
     if (igemm_prepare(dd, p, BM, BN)) return -1;
-    return p.dma ? p.nst + (p.ws ? 100 : 0) : 0;
+    return p.dma ? p.nst + 100 * p.ws : 0;
 }
 
 extern "C" int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* dd) {
@@ -600,7 +613,9 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     // BX: the 128x128 image leaves room for one block per CU, so that tile takes 8 waves for every prologue
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
                     (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
-    if (p.dma && p.ws) {
+    if (p.dma && p.ws == 2) {
+        rc = igemm_launch_dma_lw(BM, BN, p.nst, d.split_parts, grid, st, p);
+    } else if (p.dma && p.ws) {
         rc = igemm_launch_dma_ws(BM, BN, p.nst, d.split_parts, p.ws_blocks, st, p);
     } else if (p.dma) {
         rc = igemm_launch_dma(BM, BN, p.nst, d.split_parts, grid, st, p);

@@ -26,13 +26,18 @@
 
 namespace aldm {
 
-constexpr int ws_acc_floats(int BM, int BN) { return 4 * (BM / 64) * 32 * ((BN / 64) * 32 + 4); }
-constexpr int ws_lds_bytes(int BM, int BN, int NST, int NP) {
-    return NST * dma_stage_slots(BM, BN, NP) * 16 + ws_acc_floats(BM, BN) * 4;
+constexpr int ws_lds_bytes_(int BM, int BN, int NST, int NP) {
+    return NST * dma_stage_slots(BM, BN, NP) * 16 + 4 * (BM / 64) * 32 * ((BN / 64) * 32) * 4;
 }
+// hand-off buffer: the block's BM x BN accumulators, row pitch = the wave slab's width (no padding: a half wave writes 32
+// consecutive floats of one row, a ds_read_b128 lane group reads 16 distinct float4 of two rows — conflict free as it is)
+constexpr int ws_acc_floats(int BM, int BN) { return 4 * (BM / 64) * 32 * ((BN / 64) * 32); }
+constexpr int ws_blocks_per_cu(int BM, int BN, int NST, int NP) { return 2 * ws_lds_bytes_(BM, BN, NST, NP) <= 160 * 1024 ? 2 : 1; }
+constexpr int ws_lds_bytes(int BM, int BN, int NST, int NP) { return ws_lds_bytes_(BM, BN, NST, NP); }
 
+// Two blocks share a CU (16 waves, 128 registers each) when two rings + hand-off buffers fit the 160 KiB of LDS.
 template <int BM, int BN, int NST, int NP>
-__global__ __launch_bounds__(512, 2)
+__global__ __launch_bounds__(512, 2 * ws_blocks_per_cu(BM, BN, NST, NP))
 void igemm_dma_ws_kernel(const IgemmK p) {
     constexpr int WN = 2, NW = 4;
     constexpr int MT = BM / 64, NT = BN / 64;
@@ -42,7 +47,7 @@ void igemm_dma_ws_kernel(const IgemmK p) {
     constexpr int NB = 4 * NP * (BN / 64) / NW;
     constexpr int D = NP * RA + NB;
     constexpr int NPROD = NP == 3 ? 6 : 3;
-    constexpr int SP = NT * 32 + 4;          // hand-off row pitch (floats)
+    constexpr int SP = NT * 32;              // hand-off row pitch (floats)
     constexpr int SLAB = 32 * SP;            // one 32-row slab of one wave
     static_assert(NP == 2 || NP == 3, "2 or 3 parts");
     static_assert(BM % (16 * NW) == 0 && (4 * NP * (BN / 64)) % NW == 0, "DMA chunks must divide among the waves");

@@ -515,7 +515,7 @@ class LatentDiffusion(nn.Module):
         waveform = self.first_stage_model.vocoder.forward_cl(mel.float().contiguous())
         return waveform.cpu().detach().numpy()
 
-    def _check_candidates(self, n_gen):
+    def _check_candidates(self, n_gen, text=None):
         """Fail BEFORE sampling: n_candidate_gen_per_text > 1 ends in CLAP re-ranking (ddpm.py:1554-1568), which
         needs `self.clap` (a module with cos_similarity(waveform, text)); without it the candidates could only be
         generated and thrown away."""
@@ -524,6 +524,15 @@ class LatentDiffusion(nn.Module):
                                       "with build_clap=False: set latent_diffusion.clap to "
                                       "audioldm2_amd.clap.CLAPAudioEmbeddingClassifierFreev2(embed_mode='audio', ...) "
                                       "or pass n_candidate_gen_per_text=1")
+        if n_gen > 1 and text is not None and not isinstance(text, dict) and getattr(self.clap, "tokenize", True) is None:
+            raise RuntimeError("n_candidate_gen_per_text > 1: the CLAP re-ranker has no tokenizer (RobertaTokenizer could not "
+                               "be loaded offline) — it would fail only AFTER the whole sampling run; set latent_diffusion.clap."
+                               "tokenize to a RoBERTa tokenizer or pass n_candidate_gen_per_text=1")
+        if n_gen > 1 and not getattr(self.clap, "weights_loaded", True) and not getattr(self, "_warned_clap_random", False):
+            import warnings
+            warnings.warn("n_candidate_gen_per_text > 1 with a CLAP re-ranker whose weights were never loaded (the checkpoint "
+                          "had no `clap.*` entries): candidates are ranked by a randomly initialised model")
+            self._warned_clap_random = True
 
     @torch.no_grad()
     def generate_batch(self, batch, ddim_steps=200, ddim_eta=1.0, x_T=None, n_gen=1,
@@ -533,7 +542,7 @@ class LatentDiffusion(nn.Module):
         draws the posterior sample (one CPU randn of the latent shape, distributions.py:37-41) only to
         read its batch size; we replay the draw and skip the 345 GFLOP encode."""
         assert x_T is None
-        self._check_candidates(n_gen)
+        self._check_candidates(n_gen, batch.get("text"))
         use_ddim = ddim_steps is not None
         # DDPM.get_input maps first_stage_key "fbank" to batch["log_mel_spec"] (ddpm.py:482-522)
         fb = batch["log_mel_spec"] if self.first_stage_key == "fbank" else batch[self.first_stage_key]
@@ -592,7 +601,12 @@ class LatentDiffusion(nn.Module):
                                                     savepath="", bs=None, name=batch.get("fname"), save=False)
         if n_gen > 1:
             # ddpm.py:1554-1568: keep, per prompt, the candidate whose CLAP audio embedding is closest to the text's
-            similarity = self.clap.cos_similarity(torch.FloatTensor(waveform).squeeze(1), text)
+            if shard is not None:   # consume the GLOBAL batch's unconditional-probability draws, keep our rows' decisions
+                self.clap.decision_shard = (B0 * n_gen, rows.tolist())
+            try:
+                similarity = self.clap.cos_similarity(torch.FloatTensor(waveform).squeeze(1), text)
+            finally:
+                self.clap.decision_shard = None
             best = []
             for i in range(Bp):
                 cand = similarity[i::Bp]
@@ -610,7 +624,7 @@ class LatentDiffusion(nn.Module):
         """ddpm.py:1573-1676 (inpainting / super-resolution): VAE-encode the given mel -> x0, keep the
         unmasked latent region (DDIM blends q_sample(x0, t) back in every step), regenerate the rest."""
         assert x_T is None
-        self._check_candidates(n_gen)
+        self._check_candidates(n_gen, batch.get("text"))
         use_ddim = ddim_steps is not None
         fb = batch["log_mel_spec"] if self.first_stage_key == "fbank" else batch[self.first_stage_key]
         x = fb.unsqueeze(1).float().contiguous().to(self.device)  # DDPM.get_input: [B, 1, T, F]

@@ -119,3 +119,38 @@ def test_candidate_rows_keep_a_prompts_candidates_on_one_rank_and_rerank_like_on
         assert chosen == single
     # one candidate per prompt: the rows are the contiguous slice the n_gen == 1 path has always used
     assert candidate_rows(7, 1, 1, 2).tolist() == list(range(*shard_range(7, 1, 2)))
+
+
+def test_sharded_reranking_consumes_the_global_unconditional_draws():
+    """`cos_similarity` replaces each row's CLAP embedding by the empty-text embedding with probability 0.1 — one
+    `torch.rand(1)` per row of the GLOBAL candidate batch (audio pass, then text pass; encoders/modules.py:728-735).  A prompt
+    shard must draw the global batch's uniforms and apply its rows' decisions, or its candidates are ranked with other rows
+    replaced than in the single-process run."""
+    import types
+    from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2 as Clap
+    from audioldm2_amd.dist import candidate_rows
+    B, n_gen, world = 5, 3, 2
+    G = B * n_gen
+
+    def fake(decision_shard):
+        ns = types.SimpleNamespace(unconditional_prob=0.5, unconditional_token=torch.full((1, 4), -7.0),
+                                   decision_shard=decision_shard)
+        ns.make_decision = lambda pr: float(torch.rand(1)) < pr
+        return ns
+
+    def two_passes(ns, emb):   # cos_similarity: audio embeddings, then text embeddings
+        a = Clap._draw_unconditional(ns, emb.clone())
+        t = Clap._draw_unconditional(ns, emb.clone() + 100.0)
+        return a, t
+
+    emb = torch.arange(G * 4, dtype=torch.float32).view(G, 4)
+    torch.manual_seed(123)
+    ga, gt = two_passes(fake(None), emb)
+    assert (ga[:, 0, 0] == -7.0).any() and not (ga[:, 0, 0] == -7.0).all()   # the seed replaces some rows, not all
+    end_state = torch.get_rng_state()
+    for rank in range(world):
+        rows = candidate_rows(B, n_gen, rank, world)
+        torch.manual_seed(123)
+        la, lt = two_passes(fake((G, rows.tolist())), emb[rows])
+        assert torch.equal(la, ga[rows]) and torch.equal(lt, gt[rows])
+        assert torch.equal(torch.get_rng_state(), end_state)   # and the generator ends where the single process leaves it

@@ -185,8 +185,9 @@ def test_linear_geglu_layernorm_attention_split_chain(ops):
 
 
 # ---- the persistent wave-specialised form (csrc/igemm_dma_ws.h): aldm_igemm_force_stages(100 + ring depth) -------------
-_WS_TILES = {"bf16x6": [(64, 128, 2), (64, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 3), (64, 64, 4)],
-             "bf16x3": [(64, 128, 3), (64, 128, 4), (64, 128, 5), (128, 64, 3), (128, 64, 4), (64, 64, 4), (64, 64, 6)]}
+_WS_TILES = {"bf16x6": [(64, 128, 2), (64, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)],
+             "bf16x3": [(64, 128, 2), (64, 128, 3), (64, 128, 4), (64, 128, 5), (128, 64, 2), (128, 64, 3), (128, 64, 4),
+                        (64, 64, 3), (64, 64, 4), (64, 64, 6)]}
 _OLD_STAGES = {(64, 128): 4, (128, 64): 4, (64, 64): 3}
 
 

@@ -15,9 +15,13 @@ MODE = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else
 QUICK = "--quick" in sys.argv
 ops.set_mma(MODE)
 NP = ops.split_parts()
-WS_CFGS = {2: [(64, 128, 3), (64, 128, 4), (64, 128, 5), (128, 64, 3), (128, 64, 4), (64, 64, 4), (64, 64, 6)],
-           3: [(64, 128, 2), (64, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 3), (64, 64, 4)]}[NP]
-OLD_DEFAULT_ST = {(64, 128): 4, (128, 64): 4, (64, 64): 3}
+WS_CFGS = {2: [(64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 64, 2), (128, 64, 3), (64, 64, 3), (64, 64, 4), (64, 64, 6)],
+           3: [(64, 128, 2), (64, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)]}[NP]
+OLD_DEFAULT_ST = {(64, 128): 4, (128, 64): 4, (64, 64): 3, (128, 128): 2}
+LW_CFGS = {2: [(128, 128, 2), (128, 128, 4), (64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 64, 2), (128, 64, 3), (128, 64, 4),
+               (64, 64, 2), (64, 64, 3), (64, 64, 4)],
+           3: [(128, 128, 2), (128, 128, 3), (64, 128, 2), (64, 128, 4), (128, 64, 2), (128, 64, 4), (64, 64, 2), (64, 64, 3)]}[NP]
+ONLY = os.environ.get("WS_PROBE", "ws,lw").split(",")
 
 
 def g(seed):
@@ -137,7 +141,22 @@ def main():
         t_auto = graph_time(lambda: c.run())
         line = f"{c.name:52s} auto {t_auto:7.1f} (err {e_auto:.1e}) |"
         best = (t_auto, "auto")
-        for bm, bn, st in WS_CFGS:
+        for bm, bn, st in (LW_CFGS if "lw" in ONLY else []):
+            if c.kind == "geglu" and bn != 128:
+                continue
+            try:
+                y_lw = c.run((bm, bn, 200 + st))
+            except RuntimeError as e:
+                line += f" lw{bm}x{bn}s{st} n/a({str(e)[:40]})"
+                continue
+            y_old = c.run((bm, bn, OLD_DEFAULT_ST[(bm, bn)]))
+            same = torch.equal(as_float(y_lw), as_float(y_old))
+            e_lw = float((as_float(y_lw).double().cpu() - ref).abs().max() / ref.abs().max())
+            t_lw = graph_time(lambda: c.run((bm, bn, 200 + st)))
+            line += f" lw{bm}x{bn}s{st} {t_lw:6.1f}{'' if same else ' !=old'}{'' if e_lw < 5e-5 else f' ERR {e_lw:.1e}'}"
+            if t_lw < best[0]:
+                best = (t_lw, f"lw{bm}x{bn}s{st}")
+        for bm, bn, st in (WS_CFGS if "ws" in ONLY else []):
             if c.M % bm or c.N % bn or (c.kind == "geglu" and bn != 128):
                 continue
             if c.kind == "conv3" and c.rowbias is not None and (c.M // c.B) % bm:
