@@ -14,6 +14,8 @@
 #include "igemm_epilogue.h"
 #include <float.h>
 #include <stdlib.h>
+#include <string.h>
+#include <atomic>
 
 namespace aldm {
 
@@ -593,20 +595,29 @@ using namespace aldm;
 // matrix-core path of the attention kernel: -1 = default (bf16x3 since round 2: 1024x1024 self-attention 202 us on the
 // fp32 MFMA, 139 us as bf16x6, see profiles/r02_attn_ab*.txt; $ALDM_ATTN_MMA = f32 | bf16x6 | bf16x3 overrides),
 // 1 = fp32 MFMA, 2 = bf16x6, 3 = bf16x3
-static thread_local int g_attn_mma = -1;
+// PROCESS-wide (a thread_local setting silently did not reach other launch threads).
+static std::atomic<int> g_attn_mma{-1};
 static int default_attn_mode() {
+    // $ALDM_ATTN_MMA pins the attention kernel's path; otherwise it follows the engine's $ALDM_MMA (with
+    // ALDM_MMA=bf16x6 in the environment the attention used to stay on bf16x3, so "strict" runs measured a mixed mode)
     static const int v = [] {
-        const char* e = getenv("ALDM_ATTN_MMA");
-        if (e == nullptr) return 3;
-        if (e[0] == 'f') return 1;
-        return (e[0] == 'b' && e[4] == 'x' && e[5] == '6') ? 2 : 3;
+        auto parse = [](const char* e) {
+            if (e == nullptr || e[0] == 0) return 0;
+            if (strcmp(e, "f32") == 0) return 1;
+            if (strcmp(e, "bf16x6") == 0) return 2;
+            if (strcmp(e, "bf16x3") == 0) return 3;
+            fprintf(stderr, "[libaldm_hip] ignoring unknown matrix-core mode \"%s\" (f32 | bf16x6 | bf16x3)\n", e);
+            return 0;
+        };
+        int m = parse(getenv("ALDM_ATTN_MMA"));
+        if (m == 0) m = parse(getenv("ALDM_MMA"));
+        return m ? m : 3;
     }();
     return v;
 }
 extern "C" int aldm_attention_mma(int mode) {
-    const int prev = g_attn_mma;
-    if (mode == -1 || (mode >= 1 && mode <= 3)) g_attn_mma = mode;
-    return prev;
+    if (mode == -1 || (mode >= 1 && mode <= 3)) return g_attn_mma.exchange(mode);
+    return g_attn_mma.load();
 }
 
 static int attention_launch(const float* q, const float* k, const float* v, float* out, void* out_split, int parts, int B,
@@ -637,7 +648,8 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
         return e == nullptr || e[0] != '0';
     }();
     const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 64 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
-    const int amode = g_attn_mma < 0 ? default_attn_mode() : g_attn_mma;
+    const int gm = g_attn_mma.load();
+    const int amode = gm < 0 ? default_attn_mode() : gm;
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
 #define ALDM_ATTN(M_, Q_, X_, P_)                                                                                 \
     hipLaunchKernelGGL((attention_d32_kernel<M_, Q_, X_, P_>), grid, dim3(256), 0, st, q, k, v, out, Lq, Lk, ldq, \

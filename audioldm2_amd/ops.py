@@ -210,6 +210,7 @@ def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act
 # bracketed by events on the launch stream and recorded as (what, BM, BN, flops, ev_start, ev_end,
 # (M, N, K, taps, C2, has_pre, pre_act, batch, splits)).
 PROFILE = None
+ATTN_PROFILE = None   # when a list: every ops.attention launch as (B, heads, Lq, Lk, masked, flops, ev_start, ev_end)
 
 
 # Split-K scratch (caller-owned, see aldm_igemm_ws_floats): ONE grow-only buffer per device.  Launches
@@ -298,7 +299,8 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     _l.check(lib.aldm_igemm(C.byref(d), _stream()), what)
     e1.record()
     shape = (d.B * d.OH * d.OW, d.N, d.K, d.KH * d.KW, d.C2, int(bool(d.pre_scale)), d.pre_act, d.batch,
-             sp.value * 10 + kg.value, int(bool(d.a_split)), int(bool(d.out)), int(bool(d.out_split)))
+             sp.value * 10 + kg.value, int(bool(d.a_split)), int(bool(d.out)), int(bool(d.out_split)), d.split_parts or 3,
+             int(d.epi_mode == _l.EPI_GEGLU), int(bool(d.res)))
     PROFILE.append((what, bm.value, bn.value, fl.value, e0, e1, shape,
                     _kernel_name(d, bm.value, bn.value, kg.value, bool(mma.value))))
 
@@ -321,6 +323,8 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
     if d.a_split:
         nst = _l.load().aldm_igemm_plan_stages(C.byref(d))
+        if nst >= 200:   # loader waves (csrc/igemm_dma_lw.h; rocprofv3 appends the blocks-per-CU template argument)
+            return f"igemm_dma_lw_kernel<{bm}, {bn}, {nst - 200}, {4 if bm == 256 else 2}, {d.split_parts or 3}>"
         if nst >= 100:   # the persistent wave-specialised form (csrc/igemm_dma_ws.h)
             return f"igemm_dma_ws_kernel<{bm}, {bn}, {nst - 100}, {d.split_parts or 3}>"
         return f"igemm_dma_kernel<{bm}, {bn}, {nst}, {4 if bm == 256 else 2}, {d.split_parts or 3}>"
@@ -679,14 +683,23 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *,
     out = None if split_out == "only" else torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
     if mask is not None:
         mask = mask.to(torch.float32).reshape(B, Lk).contiguous()
+    ev = None
+    if ATTN_PROFILE is not None:   # bench.py's attention roofline: 2 products of 2*Lq*Lk*32 flops per (sample, head)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if not split_out:
         _l.check(_l.load().aldm_attention_d32(qp, kp, vp, out.data_ptr(), B, heads, Lq, Lk, ldq, ldk, ldv,
                                               heads * 32, _p(mask), scale, _stream()), "attention_d32")
-        return out
-    so = SplitT.empty((B, Lq, heads * 32), q.device)
-    _l.check(_l.load().aldm_attention_d32_split(qp, kp, vp, _p(out), so.data_ptr(), so.parts, B, heads, Lq, Lk, ldq, ldk,
-                                                ldv, heads * 32, _p(mask), scale, _stream()), "attention_d32_split")
-    return so if split_out == "only" else (out, so)
+        res = out
+    else:
+        so = SplitT.empty((B, Lq, heads * 32), q.device)
+        _l.check(_l.load().aldm_attention_d32_split(qp, kp, vp, _p(out), so.data_ptr(), so.parts, B, heads, Lq, Lk, ldq,
+                                                    ldk, ldv, heads * 32, _p(mask), scale, _stream()), "attention_d32_split")
+        res = so if split_out == "only" else (out, so)
+    if ev is not None:
+        ev[1].record()
+        ATTN_PROFILE.append((B, heads, Lq, Lk, mask is not None, 4.0 * B * heads * Lq * Lk * 32, ev[0], ev[1]))
+    return res
 
 
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:

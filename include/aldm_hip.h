@@ -14,8 +14,11 @@
  *   - return value: 0 on success, negative on error; aldm_last_error() gives the message
  *     (thread local).  Host wrappers turn that into a Python RuntimeError, mirroring the
  *     reference's plain-exception convention (e.g. openaimodel.py:858-860 asserts).
- *   - all arithmetic is IEEE fp32 (operands and accumulation): contractions run on
- *     v_mfma_f32_32x32x2_f32, which is bit-identical to an fp32 fmaf chain.
+ *   - operands, accumulators and every stored tensor are IEEE fp32; HOW an fp32 x fp32 product of a contraction is
+ *     evaluated depends on the matrix-core mode: "f32" = v_mfma_f32_32x32x2_f32 (exact fp32 products,
+ *     bit-identical to an fmaf chain); "bf16x6" = 6 bf16 MFMA partial products of exact 3-part operand splits (fp32
+ *     grade, 2.4e-7 rms vs fp64); "bf16x3" (the DEFAULT for launches over pre-split operands and for attention) = 3
+ *     partial products of (hi, mid) parts rounded to nearest: 16 significant bits per operand, 4.4e-6 rms per contraction.
  */
 #ifndef ALDM_HIP_H
 #define ALDM_HIP_H
@@ -248,9 +251,10 @@ int aldm_attention_d32(const float* q, const float* k, const float* v, float* ou
 int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
                              int parts, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                              const float* mask, float scale, void* stream);
-/* Matrix-core path of aldm_attention_d32 on this thread: 1 = fp32 MFMA, 2 = "bf16x6" (both products as 6 bf16 partial
+/* Matrix-core path of aldm_attention_d32, PROCESS wide: 1 = fp32 MFMA, 2 = "bf16x6" (both products as 6 bf16 partial
  * products of exact 3-part operand splits), 3 = "bf16x3" ((hi, mid) rounded to nearest, 3 partial products), -1 =
- * default (bf16x3 unless $ALDM_ATTN_MMA says "f32" / "bf16x6").  Returns the previous mode.                      */
+ * default: $ALDM_ATTN_MMA if set, else the engine's $ALDM_MMA, else bf16x3 ("f32" | "bf16x6" | "bf16x3"; anything else is
+ * reported on stderr and ignored).  Returns the previous mode; other values only query.                         */
 int aldm_attention_mma(int mode);
 /* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,
  * window_size = `window` <= 8, shared heads): per head h (channels [h*d, (h+1)*d), d <= 128)

@@ -635,3 +635,33 @@ def test_error_reporting(ops):
     w = torch.randn(8, 6, 1, 1)
     with pytest.raises(RuntimeError, match="multiples of 4"):
         ops.conv(x, ops.pack_conv(w))
+
+
+def test_env_selected_strict_mode_reaches_the_attention_kernel():
+    """`ALDM_MMA=bf16x6` (the documented strict mode) in the ENVIRONMENT must put the attention kernel on bf16x6
+    as well, not only ops.set_mma(): a fresh process with the variable set gives fp32-grade attention (error vs fp64 ~2e-7;
+    the bf16x3 default sits at ~4e-6 on these inputs)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import torch, torch.nn.functional as F
+from audioldm2_amd import ops
+g = torch.Generator().manual_seed(7)
+B, H, L = 2, 8, 256
+q, k, v = (torch.randn(B, L, H * 32, generator=g) for _ in range(3))
+o = ops.attention(q.cuda(), k.cuda(), v.cuda(), H).double().cpu()
+sh = lambda t: t.double().view(B, L, H, 32).transpose(1, 2)
+ref = F.scaled_dot_product_attention(sh(q), sh(k), sh(v)).transpose(1, 2).reshape(B, L, H * 32)
+print("ERR", float((o - ref).abs().max() / ref.abs().max()))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs = {}
+    for mode in ("bf16x6", "bf16x3"):
+        env = dict(os.environ, ALDM_MMA=mode, PYTHONPATH=root)
+        env.pop("ALDM_ATTN_MMA", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        errs[mode] = float([l for l in out.stdout.splitlines() if l.startswith("ERR")][0].split()[1])
+    assert errs["bf16x6"] < 1e-6, errs
+    assert errs["bf16x3"] > 2 * errs["bf16x6"], errs   # the two modes really are different kernels
