@@ -101,6 +101,46 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// The same update with the step's coefficient row and noise row selected ON THE DEVICE by a step counter, in place on x:
+// one captured graph serves every step with no host-issued copies between replays.
+__global__ void ddim_step_indexed_kernel(float* __restrict__ x, const float* __restrict__ eps,
+                                         const float* __restrict__ noise_tab, const float* __restrict__ coef_tab,
+                                         const int* __restrict__ step_idx, float* __restrict__ pred_x0, int64_t n,
+                                         int coef_ld) {
+    const int s = *step_idx;
+    const float* coef = coef_tab + (int64_t)s * coef_ld;
+    const float* noise = noise_tab + (int64_t)s * n;
+    const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], c4 = coef[4], gs = coef[5];
+    const bool cfg = coef[6] != 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float e;
+        if (cfg) {
+            const float eu = eps[i], ec = eps[n + i];
+            e = eu + gs * (ec - eu);
+        } else {
+            e = eps[i];
+        }
+        const float xv = x[i];
+        const float p0 = (xv - c0 * e) / c1;
+        const float dir = c2 * e;
+        const float nz = c4 * noise[i];
+        x[i] = c3 * p0 + dir + nz;
+        if (pred_x0) pred_x0[i] = p0;
+    }
+}
+
+// last node of the step graph: counter += 1 and the NEXT step's timestep row into the UNet's static input (one block: every
+// thread reads the old counter before thread 0 stores the new one)
+__global__ void step_advance_kernel(int* __restrict__ step_idx, const float* __restrict__ t_tab, float* __restrict__ t_cur,
+                                    int nt, int steps) {
+    const int s = *step_idx + 1;
+    const int row = s < steps ? s : steps - 1;
+    for (int j = threadIdx.x; j < nt; j += blockDim.x) t_cur[j] = t_tab[(int64_t)row * nt + j];
+    __syncthreads();
+    if (threadIdx.x == 0) *step_idx = s;
+}
+
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
                              float* __restrict__ y, float alpha, float beta, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -212,6 +252,22 @@ extern "C" int aldm_ddim_step(const float* x, const float* eps, const float* noi
     hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, eps,
                        noise, coef, x_prev, pred_x0, n);
     ALDM_LAUNCH_CHECK("aldm_ddim_step");
+    return 0;
+}
+
+extern "C" int aldm_ddim_step_indexed(float* x, const float* eps, const float* noise_tab, const float* coef_tab,
+                                      const int* step_idx, float* pred_x0, int64_t n, int coef_ld, void* stream) {
+    ALDM_CHECK(x && eps && noise_tab && coef_tab && step_idx && n > 0 && coef_ld >= 7, "aldm_ddim_step_indexed: bad args");
+    hipLaunchKernelGGL(ddim_step_indexed_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, eps, noise_tab,
+                       coef_tab, step_idx, pred_x0, n, coef_ld);
+    ALDM_LAUNCH_CHECK("aldm_ddim_step_indexed");
+    return 0;
+}
+
+extern "C" int aldm_step_advance(int* step_idx, const float* t_tab, float* t_cur, int nt, int steps, void* stream) {
+    ALDM_CHECK(step_idx && t_tab && t_cur && nt > 0 && steps > 0, "aldm_step_advance: bad args");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_idx, t_tab, t_cur, nt, steps);
+    ALDM_LAUNCH_CHECK("aldm_step_advance");
     return 0;
 }
 

@@ -107,12 +107,18 @@ def drop_graph_entries(cache: dict) -> None:
 
 
 class _NoiseFeed:
-    """Streams the per-step host noise to the GPU in chunks, overlapping the CPU generator (the
-    reference's RNG stream, drawn strictly in its order) and the PCIe upload with the UNet steps of the
-    previous chunk: chunk c+1 is drawn and uploaded on a side stream while the GPU runs chunk c.
-    Device buffers hold all steps; `wait(i)` makes the current stream wait for step i's chunk."""
+    """Streams the per-step host noise to the GPU in chunks.  A DRAWER THREAD consumes the CPU generator (the reference's RNG
+    stream, strictly in its order: only this thread draws while a sampling run is in flight) into pinned staging rows and
+    issues the PCIe uploads on a side stream, running up to `len(pin)` chunks ahead of the GPU; the launching thread only
+    makes its stream wait for a chunk's upload event (`wait(i)`).  Round 2 drew on the launching thread between graph replays:
+    with prompt sharding every rank draws the GLOBAL batch (7 ms per step at 8 ranks x 8 prompts against a 16 ms GPU step,
+    profiles/r02_host_noise_cost.txt) — one kernel speed-up away from bounding the job.  `torch.randn` releases the GIL.
+    Device buffers hold all steps (`noise_buf` / `qnoise_buf`: write into these — the static inputs of a cached step graph —
+    instead of allocating); `close()` joins the thread: after it the generator is where the reference leaves it."""
 
-    def __init__(self, draw, steps, shape, with_mask, temperature, dev, chunk=8, mask_first=True):
+    def __init__(self, draw, steps, shape, with_mask, temperature, dev, chunk=8, mask_first=True, noise_buf=None,
+                 qnoise_buf=None, threaded=None):
+        import threading
         self.draw, self.steps, self.with_mask, self.temperature = draw, steps, with_mask, temperature
         self.mask_first = mask_first  # DDIM draws the q_sample noise before the step noise, DDPM after
         # chunk boundaries: the first chunk is ONE step so the GPU starts right away, then `chunk` steps
@@ -120,21 +126,31 @@ class _NoiseFeed:
         while self.bounds[-1] < steps:
             self.bounds.append(min(steps, self.bounds[-1] + chunk))
         self.chunk = chunk
-        self.noise = torch.empty((steps,) + tuple(shape), device=dev, dtype=torch.float32)
-        self.qnoise = torch.empty_like(self.noise) if with_mask else None
-        nbuf = 2
+        self.noise = noise_buf if noise_buf is not None else torch.empty((steps,) + tuple(shape), device=dev,
+                                                                         dtype=torch.float32)
+        assert self.noise.shape == (steps,) + tuple(shape)
+        self.qnoise = (qnoise_buf if qnoise_buf is not None else torch.empty_like(self.noise)) if with_mask else None
+        nbuf = 3
         self.pin = [torch.empty((chunk,) + tuple(shape)).pin_memory() for _ in range(nbuf)]
         self.qpin = [torch.empty((chunk,) + tuple(shape)).pin_memory() for _ in range(nbuf)] if with_mask else None
         self.stream = torch.cuda.Stream(device=dev)
-        # the device buffers were just allocated on the current stream: the caching allocator may hand out a block that
-        # kernels already queued there (the previous run's noise copies) still read, so the upload stream must not
-        # start writing before the current stream has reached this point
+        # the device buffers may have been handed out while kernels already queued on the current stream (the previous run's
+        # noise copies / step graph) still read them: the upload stream must not start writing before the current stream has
+        # reached this point
         self.stream.wait_stream(torch.cuda.current_stream())
         self.noise.record_stream(self.stream)
         if self.qnoise is not None:
             self.qnoise.record_stream(self.stream)
         self.events = {}
         self.produced = 0  # chunks drawn so far
+        self.dev_index = torch.cuda.current_device()   # the drawer thread must issue its uploads on THIS device
+        self.error = None
+        self.cv = threading.Condition()
+        self.threaded = (os.environ.get("ALDM_NOISE_THREAD", "1") != "0") if threaded is None else threaded
+        self.thread = None
+        if self.threaded:
+            self.thread = threading.Thread(target=self._run, name="aldm-noise-drawer", daemon=True)
+            self.thread.start()
 
     def _draw_into(self, dst):
         """One reference-ordered draw into a (pinned) staging row."""
@@ -144,10 +160,7 @@ class _NoiseFeed:
         else:
             dst.numpy()[...] = d().numpy()   # plain memcpy, no thread pool
 
-    def produce_next(self):
-        c = self.produced
-        if c + 1 >= len(self.bounds):
-            return
+    def _produce(self, c):
         lo, hi = self.bounds[c], self.bounds[c + 1]
         slot = c % len(self.pin)
         prev = self.events.get(c - len(self.pin))
@@ -155,8 +168,7 @@ class _NoiseFeed:
             prev.synchronize()  # the upload that last used this pinned slot is done
         # Host side of the RNG contract.  The draws go STRAIGHT into the pinned staging rows (`torch.randn(out=...)`: same
         # generator stream, no intermediate tensor): a 1 MB `Tensor.copy_` through torch's intra-op thread pool costs
-        # ~20 ms on a many-core host (measured: 19 ms with 8 threads on 8 busy vCPUs vs 0.02 ms with 4) — 200 of them
-        # per job had become the bound of the whole job (5.3 s) once the UNet step dropped under 25 ms.
+        # ~20 ms on a many-core host (measured: 19 ms with 8 threads on 8 busy vCPUs vs 0.02 ms with 4).
         for s in range(lo, hi):  # reference order per step
             if self.with_mask and self.mask_first:
                 self._draw_into(self.qpin[slot][s - lo])
@@ -171,19 +183,56 @@ class _NoiseFeed:
                 self.qnoise[lo:hi].copy_(self.qpin[slot][:hi - lo], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        self.events[c] = ev
+        return ev
+
+    def _run(self):   # drawer thread
+        try:
+            torch.cuda.set_device(self.dev_index)
+            for c in range(len(self.bounds) - 1):
+                ev = self._produce(c)
+                with self.cv:
+                    self.events[c] = ev
+                    self.produced = c + 1
+                    self.cv.notify_all()
+        except BaseException as e:  # surfaced by the launching thread's next wait()
+            with self.cv:
+                self.error = e
+                self.cv.notify_all()
+
+    def produce_next(self):
+        """Unthreaded mode (ALDM_NOISE_THREAD=0 / tests): draw + upload the next chunk on the calling thread."""
+        if self.threaded:
+            return
+        c = self.produced
+        if c + 1 >= len(self.bounds):
+            return
+        self.events[c] = self._produce(c)
         self.produced = c + 1
 
     def wait(self, i):
-        """Make the current stream wait for step i's noise; returns True when i opens a chunk (the caller
-        then draws the next chunk after launching this step)."""
+        """Make the current stream wait for step i's noise; returns True when i opens a chunk."""
         c = 0 if i == 0 else 1 + (i - 1) // self.chunk
-        while self.produced <= c:
-            self.produce_next()
+        if self.threaded:
+            with self.cv:
+                while self.produced <= c and self.error is None:
+                    self.cv.wait(timeout=60.0)
+                if self.error is not None:
+                    raise RuntimeError(f"noise drawer thread failed: {self.error!r}")
+        else:
+            while self.produced <= c:
+                self.produce_next()
         first = i == self.bounds[c]
         if first:
             torch.cuda.current_stream().wait_event(self.events[c])
         return first
+
+    def close(self):
+        """Join the drawer: every draw of the run has been consumed from the generator (callers draw again afterwards)."""
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+            if self.error is not None:
+                raise RuntimeError(f"noise drawer thread failed: {self.error!r}")
 
 
 def host_drawer(shape, noise_shard=None):
@@ -313,9 +362,6 @@ class DDIMSampler(object):
         draw = self._drawer(tuple(shape))
         img_h = draw() if x_T is None else x_T.detach().float().cpu()
         img = img_h.to(dev).contiguous()
-        feed = _NoiseFeed(draw, total_steps, tuple(shape), mask is not None, temperature, dev)
-        feed.produce_next()
-        noise, qn = feed.noise, feed.qnoise
         # device tables in loop order (i = 0 is the noisiest step, index = total_steps - 1)
         order = [total_steps - i - 1 for i in range(total_steps)]
         coef = torch.zeros(total_steps, 8)
@@ -324,7 +370,7 @@ class DDIMSampler(object):
         coef[:, 6] = 1.0 if use_cfg else 0.0
         coef = coef.to(dev)
         nrep = 2 if use_cfg else 1
-        t_tab = torch.from_numpy(np.ascontiguousarray(time_range)).float()[:, None].repeat(1, nrep * b).to(dev)
+        t_tab = torch.from_numpy(np.ascontiguousarray(time_range)).float()[:, None].repeat(1, nrep * b).to(dev).contiguous()
 
         if mask is not None:
             assert x0 is not None
@@ -343,12 +389,16 @@ class DDIMSampler(object):
         # that run skips the eager first step and the re-capture (~0.1 s per job).  New conditioning is
         # copied INTO the captured tensors and the cross-attention K/V projections are recomputed in
         # place; invalidate_packed() (weights changed) drops the cache.
+        # The graph's per-step inputs are selected ON THE DEVICE: a step counter indexes the coefficient table and the noise
+        # buffer (aldm_ddim_step_indexed, in place on x) and the graph's last node advances the counter and writes the next
+        # step's timestep row (aldm_step_advance) — between two replays the host issues nothing but a stream wait on the
+        # noise upload event, once per 8 steps (round 2 issued three copies per step from the host).
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
         can_cache = (prepared is not None and mask is None and self.use_graph and hasattr(unet, "refresh_context_kv")
                      and os.environ.get("ALDM_NO_GRAPH_CACHE", "0") != "1")
         key = None
         if can_cache:
-            key = (tuple(shape), tuple(tuple(c.shape) for c in prepared["ctxs"]),
+            key = (tuple(shape), total_steps, tuple(tuple(c.shape) for c in prepared["ctxs"]),
                    None if prepared["y"] is None else tuple(prepared["y"].shape))
         ent = unet._graph_cache.get(key) if can_cache else None
         if ent is not None and ent.get("kv") is None:
@@ -363,10 +413,13 @@ class DDIMSampler(object):
                 ent["prepared"]["y"].copy_(prepared["y"])
             unet.refresh_context_kv(ent["kv"])  # in place: the captured graph keeps reading these buffers
             ent["x_cur"].copy_(img)
+            ent["coef_all"].copy_(coef)
+            ent["t_tab"].copy_(t_tab)
         else:
             # static buffers = the graph's inputs
-            ent = {"x_cur": img.clone(), "x_next": torch.empty_like(img), "pred_x0": torch.empty_like(img),
-                   "t_cur": t_tab[0].clone(), "coef_cur": coef[0].clone(), "noise_cur": torch.empty_like(img),
+            ent = {"x_cur": img.clone(), "pred_x0": torch.empty_like(img), "t_cur": t_tab[0].clone(),
+                   "step_idx": torch.zeros(1, device=dev, dtype=torch.int32), "coef_all": coef.clone(), "t_tab": t_tab.clone(),
+                   "noise_all": torch.empty((total_steps,) + tuple(shape), device=dev, dtype=torch.float32),
                    "prepared": prepared}
 
             def step(e=ent):
@@ -382,39 +435,44 @@ class DDIMSampler(object):
                         eps = torch.stack([e_u, e_c]).contiguous()
                 else:
                     eps = self.model.apply_model(x_c, e["t_cur"][:b].long(), cond).contiguous()
-                ops.ddim_step(x_c, eps, e["noise_cur"], e["coef_cur"], e["x_next"], e["pred_x0"])
-                x_c.copy_(e["x_next"])
+                ops.ddim_step_indexed(x_c, eps, e["noise_all"], e["coef_all"], e["step_idx"], e["pred_x0"])
+                ops.step_advance(e["step_idx"], e["t_tab"], e["t_cur"])
             ent["run_step"] = GraphStepper(step, self.use_graph)
             if can_cache:
                 drop_graph_entries(unet._graph_cache)  # one geometry at a time: the graph pins its activation pool
                 unet._graph_cache[key] = ent
-        x_cur, pred_x0, t_cur, coef_cur, noise_cur = (ent["x_cur"], ent["pred_x0"], ent["t_cur"], ent["coef_cur"],
-                                                      ent["noise_cur"])
+        ent["step_idx"].zero_()
+        ent["t_cur"].copy_(ent["t_tab"][0])
+        x_cur, pred_x0 = ent["x_cur"], ent["pred_x0"]
+        # the per-step draws are streamed by a drawer thread straight into the graph's static noise buffer (see _NoiseFeed)
+        feed = _NoiseFeed(draw, total_steps, tuple(shape), mask is not None, temperature, dev, noise_buf=ent["noise_all"])
+        feed.produce_next()
+        qn = feed.qnoise
         run_step = ent["run_step"]
         intermediates = {"x_inter": [img], "pred_x0": [img]}
-        for i, step_t in enumerate(time_range):
-            index = total_steps - i - 1
-            opens_chunk = feed.wait(i)  # current stream waits for the upload of step i's noise chunk
-            t_cur.copy_(t_tab[i])
-            coef_cur.copy_(coef[i])
-            noise_cur.copy_(noise[i])
-            if mask is not None:
-                # img = q_sample(x0, ts)*mask + (1-mask)*img   (ddim.py:226-231, ddpm.py:430-436)
-                ops.inpaint_blend(x_cur, x0_d, qn[i], mask_d, blend_coef[i])
-            run_step()  # eager the first time, then one HIP-graph replay per step
-            if can_cache and ent.get("kv") is None:
-                # after the eager first step: the K/V projections of this run's contexts exist; the cache entry owns
-                # them from here on (the graph captured at the next step reads these very buffers)
-                ent["kv"] = unet.collect_context_kv(ent["prepared"]["ctxs"])
-            if opens_chunk:
-                feed.produce_next()  # draw + upload the NEXT chunk while the GPU works on this one
-            if callback:
-                callback(i)
-            if img_callback:
-                img_callback(pred_x0, i)
-            if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates["x_inter"].append(x_cur.clone())
-                intermediates["pred_x0"].append(pred_x0.clone())
+        try:
+            for i, step_t in enumerate(time_range):
+                index = total_steps - i - 1
+                opens_chunk = feed.wait(i)  # current stream waits for the upload of step i's noise chunk
+                if mask is not None:
+                    # img = q_sample(x0, ts)*mask + (1-mask)*img   (ddim.py:226-231, ddpm.py:430-436)
+                    ops.inpaint_blend(x_cur, x0_d, qn[i], mask_d, blend_coef[i])
+                run_step()  # eager the first time, then one HIP-graph replay per step
+                if can_cache and ent.get("kv") is None:
+                    # after the eager first step: the K/V projections of this run's contexts exist; the cache entry owns
+                    # them from here on (the graph captured at the next step reads these very buffers)
+                    ent["kv"] = unet.collect_context_kv(ent["prepared"]["ctxs"])
+                if opens_chunk:
+                    feed.produce_next()  # (unthreaded mode only) draw + upload the NEXT chunk while the GPU works on this one
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(pred_x0, i)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    intermediates["x_inter"].append(x_cur.clone())
+                    intermediates["pred_x0"].append(pred_x0.clone())
+        finally:
+            feed.close()   # the generator is past the run's last draw before anyone else draws from it
         return x_cur.clone(), intermediates
 
     @torch.no_grad()

@@ -890,6 +890,28 @@ def ddim_step(x: torch.Tensor, eps: torch.Tensor, noise: torch.Tensor, coef: tor
     return x_prev, pred_x0
 
 
+def ddim_step_indexed(x: torch.Tensor, eps: torch.Tensor, noise_tab: torch.Tensor, coef_tab: torch.Tensor,
+                      step_idx: torch.Tensor, pred_x0: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ops.ddim_step with the step's coefficient / noise rows selected on the device by the int32 counter `step_idx`, in
+    place on x (aldm_ddim_step_indexed).  noise_tab: [S, *x.shape], coef_tab: [S, >= 7]."""
+    for t, n in ((x, "x"), (eps, "eps"), (noise_tab, "noise_tab"), (coef_tab, "coef_tab")):
+        _chk(t, "ddim_indexed." + n)
+    assert step_idx.dtype == torch.int32 and step_idx.is_cuda and noise_tab.shape[1:] == x.shape and coef_tab.dim() == 2
+    assert noise_tab.shape[0] == coef_tab.shape[0]
+    _l.check(_l.load().aldm_ddim_step_indexed(x.data_ptr(), eps.data_ptr(), noise_tab.data_ptr(), coef_tab.data_ptr(),
+                                              step_idx.data_ptr(), _p(pred_x0), x.numel(), coef_tab.shape[1], _stream()),
+             "ddim_step_indexed")
+    return x
+
+
+def step_advance(step_idx: torch.Tensor, t_tab: torch.Tensor, t_cur: torch.Tensor) -> None:
+    """step_idx += 1; t_cur = t_tab[min(step_idx, S - 1)] on the device (aldm_step_advance)."""
+    _chk(t_tab, "step_advance.t_tab"); _chk(t_cur, "step_advance.t_cur")
+    assert step_idx.dtype == torch.int32 and t_tab.dim() == 2 and t_tab.shape[1] == t_cur.numel()
+    _l.check(_l.load().aldm_step_advance(step_idx.data_ptr(), t_tab.data_ptr(), t_cur.data_ptr(), t_tab.shape[1],
+                                         t_tab.shape[0], _stream()), "step_advance")
+
+
 def ddpm_step(x: torch.Tensor, eps: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor,
               x_prev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Ancestral DDPM update (ddpm.py:357-373, 1127-1181); coef: device [>=5] row, see aldm_hip.h."""

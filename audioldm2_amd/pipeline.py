@@ -465,22 +465,25 @@ class LatentDiffusion(nn.Module):
             x_cur.copy_(x_next)
         run_step = GraphStepper(step, os.environ.get("ALDM_NO_GRAPH", "0") != "1")
         intermediates = [x_cur.clone()]
-        for n, i in enumerate(order):
-            opens_chunk = feed.wait(n)
-            t_cur.copy_(t_tab[n])
-            coef_cur.copy_(coef[n])
-            noise_cur.copy_(feed.noise[n])
-            run_step()
-            if opens_chunk:
-                feed.produce_next()
-            if mask is not None:
-                ops.inpaint_blend(x_cur, x0_d, feed.qnoise[n], mask_d, blend[n])
-            if i % log_every_t == 0 or i == timesteps - 1:
-                intermediates.append(x_cur.clone())
-            if callback:
-                callback(i)
-            if img_callback:
-                img_callback(x_cur, i)
+        try:
+            for n, i in enumerate(order):
+                opens_chunk = feed.wait(n)
+                t_cur.copy_(t_tab[n])
+                coef_cur.copy_(coef[n])
+                noise_cur.copy_(feed.noise[n])
+                run_step()
+                if opens_chunk:
+                    feed.produce_next()
+                if mask is not None:
+                    ops.inpaint_blend(x_cur, x0_d, feed.qnoise[n], mask_d, blend[n])
+                if i % log_every_t == 0 or i == timesteps - 1:
+                    intermediates.append(x_cur.clone())
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(x_cur, i)
+        finally:
+            feed.close()   # the drawer thread has consumed the run's last draw before anyone else uses the generator
         if return_intermediates:
             return x_cur.clone(), intermediates
         return x_cur.clone()

@@ -187,10 +187,10 @@ def roofline_probe(ld, batch, B):
     mode = ops.MMA_MODE
     apeak = MODE_PEAK[mode]
     ag = {}
-    for B_, heads, Lq, Lk, masked, fl, e0, e1 in aprof:
+    for B_, heads, Lq, Lk, masked, afl_, e0, e1 in aprof:
         a = ag.setdefault((heads, Lq, Lk, masked), [0, 0.0, 0.0])
         a[0] += 1
-        a[1] += fl
+        a[1] += afl_
         a[2] += max(e0.elapsed_time(e1) - ev_overhead_ms, 1e-4) * 1e-3
     a_fl = sum(v[1] for v in ag.values())
     a_s = sum(v[2] for v in ag.values())

@@ -300,6 +300,14 @@ int aldm_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stre
  *   e = e_u + s*(e_c - e_u); pred_x0 = (x - c0*e)/c1; x_prev = c3*pred_x0 + c2*e + c4*noise  */
 int aldm_ddim_step(const float* x, const float* eps, const float* noise, const float* coef,
                    float* x_prev, float* pred_x0, int64_t n, void* stream);
+/* The same step with its inputs selected on the DEVICE (ABI v6): coef = coef_tab[*step_idx] (rows of coef_ld >= 7 floats),
+ * noise = noise_tab[*step_idx] (rows of n floats), x updated IN PLACE (x_prev overwrites x).  Together with
+ * aldm_step_advance it lets one captured HIP graph serve every DDIM step with no host-issued copy between replays.   */
+int aldm_ddim_step_indexed(float* x, const float* eps, const float* noise_tab, const float* coef_tab,
+                           const int* step_idx, float* pred_x0, int64_t n, int coef_ld, void* stream);
+/* *step_idx += 1 and t_cur[0..nt) = t_tab[min(*step_idx, steps-1)] (the next step's timestep row, the UNet's static input;
+ * the time_range of ddim.py:205-213 stored as floats, one row per step in loop order)                                  */
+int aldm_step_advance(int* step_idx, const float* t_tab, float* t_cur, int nt, int steps, void* stream);
 /* Ancestral DDPM step (LatentDiffusion.sample -> p_sample, ddpm.py:357-373,1127-1181), reference
  * operation order: x_recon = a*x - b*eps; mean = c1*x_recon + c2*x; x_prev = mean + s*noise with
  * coef (device) = {sqrt(1/abar_t), sqrt(1/abar_t - 1), posterior_mean_coef1, posterior_mean_coef2,
