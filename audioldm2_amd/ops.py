@@ -265,7 +265,11 @@ def _tuned_table(bx=False):
         if os.environ.get("ALDM_NO_TUNING", "0") != "1":
             for mode, name in ((False, "mi355x_igemm.json"), (True, "mi355x_igemm_bf16x6.json"),
                                ("dma", "mi355x_igemm_dma.json"), ("dma2", "mi355x_igemm_dma_bf16x3.json")):
-                path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", name)
+                # ($ALDM_TUNING_DIR: another directory of tables with the same file names — same-box A/Bs of two tunings;
+                #  a table missing there falls back to the shipped one)
+                path = os.path.join(os.environ.get("ALDM_TUNING_DIR", ""), name)
+                if not (os.environ.get("ALDM_TUNING_DIR") and os.path.exists(path)):
+                    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", name)
                 if os.path.exists(path):
                     with open(path) as f:
                         _TUNED[mode] = {k: v[:5] if mode is True else v[:4] for k, v in json.load(f)["entries"].items()}

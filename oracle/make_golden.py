@@ -29,6 +29,24 @@ def save(name, **arrs):
     print(f"  wrote {path} ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def rms64(a):
+    a = np.asarray(a, dtype=np.float64)
+    return float(np.sqrt((a ** 2).mean()))
+
+
+def between_sample_rms(ld, wav, latent):
+    """What a waveform tolerance has to be read against (VERDICT r2 "weak" #1): the rms DIFFERENCE between the waveforms of two
+    unrelated samples.  B >= 2: samples 0 and 1 of the batch; B = 1: the sample against the decode + vocode of a second,
+    unrelated latent of the same statistics (seeded)."""
+    if wav.shape[0] >= 2:
+        return rms64(wav[0].astype(np.float64) - wav[1].astype(np.float64))
+    g = torch.Generator().manual_seed(9)
+    z2 = torch.randn(latent.shape, generator=g) * latent.std() + latent.mean()
+    mel2 = ld.decode_first_stage(z2)
+    wav2 = ld.mel_spectrogram_to_waveform(mel2, savepath="", bs=None, name="x", save=False)
+    return rms64(wav[0].astype(np.float64) - wav2[0].astype(np.float64))
+
+
 def load_det(module, seed=0):
     sd = weights.make_state_dict(weights.shapes_of(module), seed=seed)
     module.load_state_dict(sd)
@@ -168,7 +186,7 @@ def _ref_latent_diffusion():
     return ld
 
 
-def gen_e2e(steps: int, B: int, name: str):
+def gen_e2e(steps: int, B: int, name: str, decimate: bool = False):
     ld = _ref_latent_diffusion()
     ld.latent_t_size = 256
     rec = {}
@@ -191,7 +209,15 @@ def gen_e2e(steps: int, B: int, name: str):
     dt = time.time() - t0
     print(f"{name}: reference generate_batch B={B} steps={steps}: {dt:.1f}s  wave {wav.shape} rms {np.sqrt((wav**2).mean()):.4f}"
           f" absmax {np.abs(wav).max():.3f}  latent std {rec['latent'].std():.3f}")
-    save(name, latent=rec["latent"], mel=rec["mel"], wave=wav, seconds=np.float32(dt), threads=np.int32(torch.get_num_threads()))
+    ld.decode_first_stage = orig_decode
+    btw = between_sample_rms(ld, wav, rec["latent"])
+    print(f"{name}: between-sample wave rms {btw:.4f} = {btw / rms64(wav):.2f} x wave rms")
+    if decimate:   # large batches: head + every 16th sample of the waveform, no mel
+        save(name, latent=rec["latent"], wave_head=wav[..., :32768], wave_dec=wav[..., ::16], wave_len=np.int64(wav.shape[-1]),
+             wave_rms=np.float64(rms64(wav)), wave_between_rms=np.float64(btw))
+    else:
+        save(name, latent=rec["latent"], mel=rec["mel"], wave=wav, seconds=np.float32(dt), threads=np.int32(torch.get_num_threads()),
+             wave_between_rms=np.float64(btw))
 
 
 def _ref_latent_diffusion_named(model_name: str, keys_json: str):
@@ -241,8 +267,11 @@ def gen_e2e_48k(steps: int, B: int, name: str):
     wav = ld.generate_batch(batch, unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
     print(f"{name}: reference generate_batch(48k) B={B} steps={steps}: {time.time()-t0:.1f}s wave {wav.shape} "
           f"rms {np.sqrt((wav**2).mean()):.4f} latent std {rec['latent'].std():.3f}")
+    ld.decode_first_stage = orig_decode
+    btw = between_sample_rms(ld, wav, rec["latent"])
+    print(f"{name}: between-sample wave rms {btw:.4f} = {btw / rms64(wav):.2f} x wave rms")
     save(name, latent=rec["latent"], wave_head=wav[..., :32768], wave_dec=wav[..., ::16],
-         wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(np.sqrt((wav.astype(np.float64) ** 2).mean())))
+         wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(rms64(wav)), wave_between_rms=np.float64(btw))
 
 
 def gen_e2e_named(model_name: str, steps: int, B: int, name: str, keys_json: str):
@@ -263,8 +292,11 @@ def gen_e2e_named(model_name: str, steps: int, B: int, name: str, keys_json: str
     wav = ld.generate_batch(cases.e2e_batch(B), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
     print(f"{name}: reference generate_batch({model_name}) B={B} steps={steps}: {time.time()-t0:.1f}s wave {wav.shape} "
           f"rms {np.sqrt((wav**2).mean()):.4f} latent std {rec['latent'].std():.3f}")
+    ld.decode_first_stage = orig_decode
+    btw = between_sample_rms(ld, wav, rec["latent"])
+    print(f"{name}: between-sample wave rms {btw:.4f} = {btw / rms64(wav):.2f} x wave rms")
     save(name, latent=rec["latent"], wave_head=wav[..., :32768], wave_dec=wav[..., ::16],
-         wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(np.sqrt((wav.astype(np.float64) ** 2).mean())))
+         wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(rms64(wav)), wave_between_rms=np.float64(btw))
 
 
 def gen_seqgen():
@@ -416,7 +448,9 @@ def gen_e2e_masked(steps: int, B: int, name: str):
     dt = time.time() - t0
     print(f"{name}: reference generate_batch_masked B={B} steps={steps}: {dt:.1f}s wave rms {np.sqrt((wav**2).mean()):.4f}"
           f" latent std {rec['latent'].std():.3f} x0 std {rec['x0'].std():.3f}")
-    save(name, x0=rec["x0"], mask=rec["mask"], latent=rec["latent"], mel=rec["mel"], wave=wav)
+    ld.decode_first_stage, ld.sample_log = orig_decode, orig_sample_log
+    btw = between_sample_rms(ld, wav, rec["latent"])
+    save(name, x0=rec["x0"], mask=rec["mask"], latent=rec["latent"], mel=rec["mel"], wave=wav, wave_between_rms=np.float64(btw))
 
 
 def gen_ancestral(T: int, B: int, name: str):
@@ -471,5 +505,14 @@ if __name__ == "__main__":
         gen_clap_text()
     if "all" in what or "htsat" in what:
         gen_htsat()
+    # round 3 (VERDICT r2 next #3e): BASELINE config 2's batch, and configs 3 / 4 / 5 at 20 steps, B = 2
+    if "all" in what or "e2e5b8" in what:
+        gen_e2e(5, 8, "e2e_full_5step_b8", decimate=True)
+    if "all" in what or "e2e48k20" in what:
+        gen_e2e_48k(20, 2, "e2e_48k_20step_b2")
+    if "all" in what or "e2espeech20" in what:
+        gen_e2e_named("audioldm2-speech-gigaspeech", 20, 2, "e2e_speech_20step_b2", "e2espeech_statedict_keys.json")
+    if "all" in what or "e2elarge20" in what:
+        gen_e2e_named("audioldm2-full-large-1150k", 20, 2, "e2e_large_20step_b2", "e2elarge_statedict_keys.json")
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")
