@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                                                          int chunk_px, float* __restrict__ ws, float eps,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         float* __restrict__ scale, float* __restrict__ shift, int gpb) {
+                                                         float* __restrict__ scale, float* __restrict__ shift, int gpb,
+                                                         char* __restrict__ dst = nullptr, char* __restrict__ dst_raw = nullptr,
+                                                         int parts = 3, int act = ALDM_ACT_NONE) {
     const int C = C1 + C2;
     const int Cg4 = (C / G) >> 2;
     const int b = blockIdx.y;
@@ -172,11 +174,61 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             fin[tid][1] = (float)(1.0 / sqrt(var + (double)eps));
         }
         __syncthreads();
+        __shared__ float lsc[256], lsh[256];   // this block's channel slab (gpb * Cg <= 256 channels when dst is set)
         for (int c = g_lo * Cg + tid; c < (g_lo + gpb) * Cg; c += 256) {
             const int g = c / Cg - g_lo;
             const float sc = fin[g][1] * (gamma ? gamma[c] : 1.f);
+            const float sh = (beta ? beta[c] : 0.f) - fin[g][0] * sc;
             scale[(int64_t)b * C + c] = sc;
-            shift[(int64_t)b * C + c] = (beta ? beta[c] : 0.f) - fin[g][0] * sc;
+            shift[(int64_t)b * C + c] = sh;
+            if (dst) {
+                lsc[c - g_lo * Cg] = sc;
+                lsh[c - g_lo * Cg] = sh;
+            }
+        }
+        if (dst) {
+            // GroupNorm apply + activation + operand split of the block's own slab, in the same launch (the slab was just read
+            // for the statistics: it comes back from L2).  Same arithmetic, in the same order, as split_rows_kernel — the
+            // image is bitwise the one aldm_groupnorm_stats + aldm_split_rows write.  One thread = 8 consecutive channels
+            // of one pixel (host: slab % 8 == 0, C1 % 8 == 0, C % 32 == 0).
+            __syncthreads();
+            const int c_lo = g_lo * Cg, sw = (gpb * Cg) >> 3;
+            for (int i = tid; i < P * sw; i += 256) {
+                const int p = i / sw;
+                const int cl = (i - p * sw) << 3;
+                const int c = c_lo + cl;
+                const int64_t row = (int64_t)b * P + p;
+                const float* src = c < C1 ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                const int64_t off = (row * (C >> 5) + (c >> 5)) * (64 * parts) + (c & 31) * 2;
+                u32x2 p0[3], p1[3];
+                if (dst_raw) {
+                    split4_parts(v0, p0, parts);
+                    split4_parts(v1, p1, parts);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (q < parts)
+                            *reinterpret_cast<u32x4*>(dst_raw + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = __builtin_fmaf(v0[e], lsc[cl + e], lsh[cl + e]);
+                    v1[e] = __builtin_fmaf(v1[e], lsc[cl + 4 + e], lsh[cl + 4 + e]);
+                }
+                if (act == ALDM_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = silu_fast(v0[e]);
+                        v1[e] = silu_fast(v1[e]);
+                    }
+                }
+                split4_parts(v0, p0, parts);
+                split4_parts(v1, p1, parts);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < parts) *reinterpret_cast<u32x4*>(dst + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+            }
         }
     } else if (tid < G) {
         // fp64 partial of this chunk: {n, mean, M2} (mean needs the full precision: it is the pivot of the merge)
@@ -386,9 +438,12 @@ extern "C" int64_t aldm_gn_ws_floats(int B, int P, int C, int G) {
     return (int64_t)B * chunks * G * 6 + 2;   // {n, mean, M2} in fp64 per (sample, chunk, group), 8-byte aligned
 }
 
-extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1, int C2,
-                                    int G, float eps, const float* gamma, const float* beta,
-                                    float* scale, float* shift, float* ws, void* stream) {
+extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                               const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream);
+
+static int groupnorm_launch(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
+                            const float* gamma, const float* beta, float* scale, float* shift, float* ws, void* dst,
+                            void* dst_raw, int parts, int act, void* stream) {
     if (!x2) C2 = 0;
     const int C = C1 + C2;
     ALDM_CHECK(x1 && scale && shift && ws, "aldm_groupnorm_stats: null pointer");
@@ -412,8 +467,21 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
     if ((int64_t)P * C <= fused_max && P <= 1024 && gpb <= 4) {
         const int c4b = gpb * (C / G) / 4;
         const int fcols = c4b < 256 ? c4b : 256, frows = 256 / fcols;
+        const int slab = gpb * (C / G);
+        static const bool fuse_split = [] {   // A/B override: ALDM_GN_SPLIT_FUSED=0 keeps statistics and split in two launches
+            const char* e = getenv("ALDM_GN_SPLIT_FUSED");
+            return e == nullptr || e[0] != '0';
+        }();
+        if (dst && fuse_split && slab % 8 == 0 && slab <= 256 && C1 % 8 == 0) {
+            // statistics + apply + activation + operand split in ONE launch (round 3)
+            hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(gs, B), dim3(256), 0, st, x1, x2, P, C1, C2, G, fcols, frows, P, ws,
+                               eps, gamma, beta, scale, shift, gpb, reinterpret_cast<char*>(dst),
+                               reinterpret_cast<char*>(dst_raw), parts, act);
+            ALDM_LAUNCH_CHECK("aldm_groupnorm_split");
+            return 0;
+        }
         hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(gs, B), dim3(256), 0, st, x1, x2, P, C1, C2, G, fcols,
-                           frows, P, ws, eps, gamma, beta, scale, shift, gpb);
+                           frows, P, ws, eps, gamma, beta, scale, shift, gpb, nullptr, nullptr, 3, ALDM_ACT_NONE);
     } else {
         hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, B), dim3(256), 0, st, x1, x2, P, C1, C2, G,
                            cols, rows, chunk_px, ws, eps, gamma, beta, scale, shift, G);
@@ -421,7 +489,28 @@ extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int
                            beta, scale, shift);
     }
     ALDM_LAUNCH_CHECK("aldm_groupnorm_stats");
+    if (dst)   // the sample is too large for the one-launch form (or the slab does not split into 16-byte pieces)
+        return aldm_split_rows(x1, x2, C1, C2, (int64_t)B * P, P, scale, shift, act, dst, dst_raw, parts, stream);
     return 0;
+}
+
+extern "C" int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1, int C2,
+                                    int G, float eps, const float* gamma, const float* beta,
+                                    float* scale, float* shift, float* ws, void* stream) {
+    return groupnorm_launch(x1, x2, B, P, C1, C2, G, eps, gamma, beta, scale, shift, ws, nullptr, nullptr, 3, ALDM_ACT_NONE,
+                            stream);
+}
+
+extern "C" int aldm_groupnorm_split(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
+                                    const float* gamma, const float* beta, int act, float* scale, float* shift, float* ws,
+                                    void* dst, void* dst_raw, int parts, void* stream) {
+    if (!x2) C2 = 0;
+    ALDM_CHECK(dst != nullptr && (parts == 2 || parts == 3) && (C1 + C2) % 32 == 0 && C1 % 8 == 0 && C2 % 8 == 0,
+               "aldm_groupnorm_split: need dst, parts 2|3, (C1+C2) %% 32 == 0, C1 %% 8 == 0 (C1=%d C2=%d)", C1, C2);
+    ALDM_CHECK(act == ALDM_ACT_NONE || act == ALDM_ACT_SILU, "aldm_groupnorm_split: activation %d not supported", act);
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dst_raw)) & 15) == 0,
+               "aldm_groupnorm_split: split images must be 16-byte aligned");
+    return groupnorm_launch(x1, x2, B, P, C1, C2, G, eps, gamma, beta, scale, shift, ws, dst, dst_raw, parts, act, stream);
 }
 
 static int layernorm_launch(const float* x, float* y, void* y_split, int parts, int M, int C, const float* gamma,

@@ -82,6 +82,9 @@ _SIGS = {
                                        C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "aldm_gn_ws_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aldm_groupnorm_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_void_p]),
     "aldm_attention_mma": (C.c_int, [C.c_int]),

@@ -646,6 +646,32 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups
     return ss[0], ss[1]
 
 
+def gn_split(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int = 32, eps: float = 1e-5,
+             x2: Optional[torch.Tensor] = None, act: int = ACT_NONE, want_raw: bool = False):
+    """split(act(GroupNorm(x ++ x2))) as a SplitT — gn_stats + split_rows in one call (one launch up to 1024 pixels per
+    sample, aldm_groupnorm_split); want_raw: also split(x ++ x2)."""
+    _chk(x, "gn_split.x")
+    B = x.shape[0]
+    C1 = x.shape[-1]
+    P = x.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _chk(x2, "gn_split.x2")
+        assert x2.shape[:-1] == x.shape[:-1]
+        C2 = x2.shape[-1]
+    Cc = C1 + C2
+    lib = _l.load()
+    ws = torch.empty(lib.aldm_gn_ws_floats(B, P, Cc, groups), device=x.device, dtype=torch.float32)
+    ss = torch.empty((2, B, Cc), device=x.device, dtype=torch.float32)
+    shape = (*x.shape[:-1], Cc)
+    dst = SplitT.empty(shape, x.device)
+    raw = SplitT.empty(shape, x.device) if want_raw else None
+    _l.check(lib.aldm_groupnorm_split(x.data_ptr(), _p(x2), B, P, C1, C2, groups, eps, gamma.data_ptr(), beta.data_ptr(), act,
+                                      ss[0].data_ptr(), ss[1].data_ptr(), ws.data_ptr(), dst.data_ptr(),
+                                      None if raw is None else raw.data_ptr(), dst.parts, _stream()), "groupnorm_split")
+    return (dst, raw) if want_raw else dst
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               split_out: Optional[str] = None):
     """LayerNorm over the last dim; split_out = "only": the result as a SplitT (the next GEMM's pre-split operand),

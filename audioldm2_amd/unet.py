@@ -66,20 +66,21 @@ class ResBlock(nn.Module):
         the batched timestep-embedding projection Linear(SiLU(emb)) (openaimodel.py:244-250, :296-298),
         computed once per forward for all ResBlocks by UNetModel."""
         pk = self._prepare()
-        sc, sh = ops.gn_stats(x, *pk["gn1"], groups=32, eps=1e-5, x2=x2)
-        if ops.use_dma() and self.channels % 32 == 0:
-            # GroupNorm apply + SiLU + operand split once per element (aldm_split_rows) instead of once per conv tap in
-            # the GEMM's K loop; the convs then run on the DMA-fed kernel over pre-split operands (csrc/igemm_dma.h)
+        c2 = 0 if x2 is None else x2.shape[-1]
+        if ops.use_dma() and self.channels % 32 == 0 and x.shape[-1] % 8 == 0 and c2 % 8 == 0:
+            # GroupNorm statistics + apply + SiLU + operand split once per element (aldm_groupnorm_split: one launch up to 1024
+            # pixels per sample) instead of once per conv tap in the GEMM's K loop; the convs then run on the DMA-fed kernel
+            # over pre-split operands (csrc/igemm_dma.h)
             if pk["skip"] is None:
                 assert x2 is None
-                a1, skip = ops.split_rows(x, pre=(sc, sh), act=ACT_SILU), x
+                a1, skip = ops.gn_split(x, *pk["gn1"], groups=32, eps=1e-5, act=ACT_SILU), x
             else:
-                a1, araw = ops.split_rows(x, x2, pre=(sc, sh), act=ACT_SILU, want_raw=True)
+                a1, araw = ops.gn_split(x, *pk["gn1"], groups=32, eps=1e-5, x2=x2, act=ACT_SILU, want_raw=True)
                 skip = ops.conv(araw, pk["skip"])
             h = ops.conv(a1, pk["conv1"], pad=(1, 1), rowbias=e)
-            sc2, sh2 = ops.gn_stats(h, *pk["gn2"], groups=32, eps=1e-5)
-            a2 = ops.split_rows(h, pre=(sc2, sh2), act=ACT_SILU)
+            a2 = ops.gn_split(h, *pk["gn2"], groups=32, eps=1e-5, act=ACT_SILU)
             return ops.conv(a2, pk["conv2"], pad=(1, 1), res=skip)
+        sc, sh = ops.gn_stats(x, *pk["gn1"], groups=32, eps=1e-5, x2=x2)
         h = ops.conv(x, pk["conv1"], x2=x2, pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU, rowbias=e)
         sc2, sh2 = ops.gn_stats(h, *pk["gn2"], groups=32, eps=1e-5)
         if pk["skip"] is None:
@@ -260,14 +261,14 @@ class SpatialTransformer(nn.Module):
                             pout=ops.pack_conv(self.proj_out.weight, self.proj_out.bias))
         pk = self._pk
         B, H, W, C = x.shape
-        sc, sh = ops.gn_stats(x, *pk["gn"], groups=32, eps=1e-6)
         if ops.use_dma() and C % 32 == 0 and self.proj_in.out_channels % 32 == 0:
-            h = ops.conv(ops.split_rows(x, pre=(sc, sh)), pk["pin"]).view(B, H * W, -1)
+            h = ops.conv(ops.gn_split(x, *pk["gn"], groups=32, eps=1e-6), pk["pin"]).view(B, H * W, -1)
             hs = None
             for i, blk in enumerate(self.transformer_blocks):
                 r = blk.run(h, context, mask, want_split=i == len(self.transformer_blocks) - 1)
                 h, hs = r if isinstance(r, tuple) else (r, None)
             return ops.conv((hs if hs is not None else h).view(B, H, W, -1), pk["pout"], res=x)
+        sc, sh = ops.gn_stats(x, *pk["gn"], groups=32, eps=1e-6)
         h = ops.conv(x, pk["pin"], pre=(sc, sh)).view(B, H * W, -1)
         for blk in self.transformer_blocks:
             h = blk.run(h, context, mask)

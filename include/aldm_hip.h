@@ -230,6 +230,14 @@ int aldm_groupnorm_stats(const float* x1, const float* x2, int B, int P, int C1,
                          int G, float eps, const float* gamma, const float* beta,
                          float* scale, float* shift, float* ws, void* stream);
 int64_t aldm_gn_ws_floats(int B, int P, int C, int G);
+/* GroupNorm + activation (ALDM_ACT_NONE | ALDM_ACT_SILU) + operand split in one call (ABI v6): dst = split(act(GroupNorm(x1 ++
+ * x2))) as a split image with `parts` parts, dst_raw (optional) = split(x1 ++ x2) — the image aldm_groupnorm_stats followed by
+ * aldm_split_rows writes, bit for bit.  Samples of up to 1024 pixels run as ONE launch (a block owns whole groups: it reads its
+ * channel slab for the statistics, then normalises and splits it while it is still in L2); larger ones as the two launches.
+ * scale / shift [B, C1+C2] are written as by aldm_groupnorm_stats.                                                       */
+int aldm_groupnorm_split(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
+                         const float* gamma, const float* beta, int act, float* scale, float* shift, float* ws,
+                         void* dst, void* dst_raw, int parts, void* stream);
 /* LayerNorm over the last dim of [M, C] (attention.py:393-395), eps 1e-5                   */
 int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                    const float* beta, float eps, void* stream);

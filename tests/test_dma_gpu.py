@@ -288,3 +288,30 @@ def test_dma_ws_falls_back_when_not_eligible(ops):
             ops.linear(xs, pw)
     finally:
         ops.igemm_force(0, 0, 0)
+
+
+@pytest.mark.parametrize("B,P,C1,C2,act", [
+    (16, 1024, 256, 0, True),     # UNet level 1, 16 samples: two groups per block, one launch
+    (16, 256, 384, 384, True),    # skip concat at level 2
+    (16, 64, 640, 0, False),      # SpatialTransformer.norm at level 3 (no activation)
+    (16, 1024, 384, 128, True),   # concat with a group straddling ... the x1 / x2 seam stays piece aligned (C1 % 8 == 0)
+    (2, 1024, 128, 0, True),      # batch 2: one group per block, slab of 4 channels -> the two-launch form
+    (3, 4096, 128, 128, True),    # level 0: too many pixels for the one-launch form
+])
+def test_groupnorm_split_equals_stats_then_split_rows(ops, B, P, C1, C2, act):
+    """aldm_groupnorm_split (statistics + apply + SiLU + operand split in one launch up to 1024 pixels) writes the image of
+    aldm_groupnorm_stats followed by aldm_split_rows BIT FOR BIT, and matches F.group_norm."""
+    x1 = (torch.randn(B, P, C1, generator=g(1)) * 2 + 0.5).cuda()
+    x2 = torch.randn(B, P, C2, generator=g(2)).cuda() if C2 else None
+    ga = torch.randn(C1 + C2, generator=g(3)).cuda()
+    be = torch.randn(C1 + C2, generator=g(4)).cuda()
+    a = ops.ACT_SILU if act else ops.ACT_NONE
+    s_new, r_new = ops.gn_split(x1, ga, be, groups=32, eps=1e-5, x2=x2, act=a, want_raw=True)
+    sc, sh = ops.gn_stats(x1, ga, be, groups=32, eps=1e-5, x2=x2)
+    s_old, r_old = ops.split_rows(x1, x2, pre=(sc, sh), act=a, want_raw=True)
+    assert torch.equal(s_new.data, s_old.data) and torch.equal(r_new.data, r_old.data)
+    xc = x1 if x2 is None else torch.cat([x1, x2], -1)
+    ref = F.group_norm(xc.double().cpu().permute(0, 2, 1), 32, ga.double().cpu(), be.double().cpu(), 1e-5).permute(0, 2, 1)
+    if act:
+        ref = F.silu(ref)
+    assert rel_err(s_new.float(), ref) < (5e-6 if exact_split(ops) else 3e-5)

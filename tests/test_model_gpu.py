@@ -235,6 +235,21 @@ def ld():
     return _build_ld()
 
 
+# Waveform tolerance (VERDICT r2 "weak" #1): north_star's "within 1e-3 rms" is read against what separates two DIFFERENT
+# samples — every fixture stores `wave_between_rms`, the rms difference between the waveforms of two unrelated samples on
+# these (random-init) weights — so a pass means "1000x closer to the reference than another sample would be", not merely
+# "smaller than a constant the vocoder's biases already satisfy".  All parity here is on random-init weights, default mode
+# (bf16x3 products) unless $ALDM_MMA says otherwise.
+WAVE_REL_TO_BETWEEN = 1e-3
+
+
+def _assert_wave(err_rms, g, what=""):
+    between = float(g["wave_between_rms"])
+    assert between > 1e-2, "fixture waveforms must depend on the sample"
+    assert err_rms < 1e-3, (what, err_rms)                                   # north_star, absolute
+    assert err_rms < WAVE_REL_TO_BETWEEN * between, (what, err_rms, between)  # ... and relative to the between-sample distance
+
+
 def _report(tag, out, g):
     errs = {}
     for k in ("latent", "mel", "wave"):
@@ -275,7 +290,22 @@ def test_e2e_5step_matches_reference_generate_batch(ld):
     errs = _report("e2e 5 steps B=2", out, g)
     assert errs["latent"][0] / errs["latent"][1] < 1e-4
     assert errs["mel"][0] / errs["mel"][1] < 1e-4
-    assert errs["wave"][0] < 1e-3 and errs["wave"][0] / errs["wave"][1] < 1e-3
+    _assert_wave(errs["wave"][0], g, "e2e 5 steps")
+
+
+def test_e2e_5step_batch8_matches_reference_generate_batch(ld):
+    """BASELINE config 2's batch (8 prompts) end to end against the real reference's generate_batch (5 steps, CFG 3.5, seed
+    42): the global-batch noise draws, the 16-sample CFG pass, per-sample masks (half the batch masks its last 8 T5 keys)."""
+    g = gold("e2e_full_5step_b8")
+    out = _generate(ld, 8, 5)
+    assert out["wave"].shape == (8, 1, int(g["wave_len"]))
+    el = rms(out["latent"].double().cpu().numpy() - g["latent"]) / rms(g["latent"])
+    eh = rms(out["wave"][..., :32768].astype(np.float64) - g["wave_head"])
+    ed = rms(out["wave"][..., ::16].astype(np.float64) - g["wave_dec"])
+    report(f"e2e 5 steps B=8: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} / between-sample "
+           f"{float(g['wave_between_rms']):.3e}")
+    assert el < 1e-4
+    _assert_wave(max(eh, ed), g, "e2e 5 steps B=8")
 
 
 def test_cached_step_graph_is_refreshed_with_new_conditioning(ld):
@@ -304,19 +334,20 @@ def test_cached_step_graph_is_refreshed_with_new_conditioning(ld):
     assert rms(other.astype(np.float64) - g["wave"]) > 1e-4  # the first job really was a different job
     errs = _report("e2e 5 steps B=2 via cached graph", out, g)
     assert errs["latent"][0] / errs["latent"][1] < 1e-4
-    assert errs["wave"][0] < 1e-3 and errs["wave"][0] / errs["wave"][1] < 1e-3
+    _assert_wave(errs["wave"][0], g, "cached graph")
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "e2e_full_200step_b1.npz")), reason="200-step fixture absent")
 def test_e2e_200step_waveform_within_north_star_tolerance(ld):
     """BASELINE config 1 (1 prompt, 10 s, 200 DDIM steps, CFG 3.5, seed 42) against the reference's
-    CPU run: waveform RMS error < 1e-3 (north_star), relative RMS < 1e-2."""
+    CPU run: latent and mel within 1e-4 relative after 400 dependent UNet evaluations, waveform rms error < 1e-3 (north_star)
+    AND < 1e-3 of the distance between two unrelated samples' waveforms."""
     g = gold("e2e_full_200step_b1")
     out = _generate(ld, 1, 200)
     errs = _report("e2e 200 steps B=1", out, g)
-    assert errs["wave"][0] < 1e-3
-    assert errs["wave"][0] / errs["wave"][1] < 1e-2
-    assert errs["latent"][0] / errs["latent"][1] < 1e-2
+    assert errs["latent"][0] / errs["latent"][1] < 1e-4
+    assert errs["mel"][0] / errs["mel"][1] < 1e-4
+    _assert_wave(errs["wave"][0], g, "e2e 200 steps")
 
 
 def test_generate_batch_masked_matches_reference(ld):
@@ -344,7 +375,7 @@ def test_generate_batch_masked_matches_reference(ld):
     report(f"masked 4 steps B=1: latent rel rms {el:.2e}  wave rms_err {ew:.3e} / rms_ref {rms(g['wave']):.3e}")
     assert wave.shape == (1, 1, 163872)
     assert el < 1e-4
-    assert ew < 1e-3 and ew / rms(g["wave"]) < 1e-3
+    _assert_wave(ew, g, "masked")
 
 
 def test_ancestral_sample_matches_reference(ld):
@@ -452,11 +483,14 @@ def test_other_baseline_configs_run_end_to_end(model_name, wave_len):
     torch.cuda.empty_cache()
 
 
-def test_e2e_48k_matches_reference_generate_batch():
-    """BASELINE config 3 (audioldm_48k) end to end against the REAL reference's generate_batch fixture
-    (B=1, 2 DDIM steps, CFG 3.5, seed 42): FiLM-conditioned UNet, 4-level VAE decoder, 48 kHz HiFi-GAN."""
+@pytest.mark.parametrize("fixture,B,steps", [("e2e_48k_2step_b1", 1, 2), ("e2e_48k_20step_b2", 2, 20)])
+def test_e2e_48k_matches_reference_generate_batch(fixture, B, steps):
+    """BASELINE config 3 (audioldm_48k) end to end against the REAL reference's generate_batch fixtures
+    (B=1, 2 DDIM steps and B=2, 20 steps; CFG 3.5, seed 42): FiLM-conditioned UNet, 4-level VAE decoder, 48 kHz HiFi-GAN."""
     from audioldm2_amd.pipeline import build_model, seed_everything
-    g = gold("e2e_48k_2step_b1")
+    if not os.path.exists(os.path.join(GOLD, fixture + ".npz")):
+        pytest.skip(f"{fixture} absent")
+    g = gold(fixture)
     m = build_model(model_name="audioldm_48k")
     with open(os.path.join(GOLD, "e2e48k_statedict_keys.json")) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
@@ -473,15 +507,15 @@ def test_e2e_48k_matches_reference_generate_batch():
     m.decode_first_stage_cl = hook
     seed_everything(cases.E2E_SEED)
     m.latent_t_size = 128
-    wave = m.generate_batch(cases.e2e_batch_48k(1), unconditional_guidance_scale=3.5, ddim_steps=2, n_gen=1, duration=10)
-    assert wave.shape == (1, 1, int(g["wave_len"]))
+    wave = m.generate_batch(cases.e2e_batch_48k(B), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
+    assert wave.shape == (B, 1, int(g["wave_len"]))
     el = rms(rec["latent"].double().cpu().numpy() - g["latent"]) / rms(g["latent"])
     eh = rms(wave[..., :32768].astype(np.float64) - g["wave_head"])
     ed = rms(wave[..., ::16].astype(np.float64) - g["wave_dec"])
-    report(f"48k e2e 2 steps B=1: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} "
-           f"/ rms_ref {float(g['wave_rms']):.3e}")
+    report(f"48k e2e {steps} steps B={B}: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} "
+           f"/ rms_ref {float(g['wave_rms']):.3e} / between-sample {float(g['wave_between_rms']):.3e}")
     assert el < 1e-4
-    assert max(eh, ed) < 1e-3 and max(eh, ed) / float(g["wave_rms"]) < 1e-3
+    _assert_wave(max(eh, ed), g, fixture)
     del m
     torch.cuda.empty_cache()
 

@@ -665,3 +665,74 @@ print("ERR", float((o - ref).abs().max() / ref.abs().max()))
         errs[mode] = float([l for l in out.stdout.splitlines() if l.startswith("ERR")][0].split()[1])
     assert errs["bf16x6"] < 1e-6, errs
     assert errs["bf16x3"] > 2 * errs["bf16x6"], errs   # the two modes really are different kernels
+
+
+# ---- bf16x3 under trained-like statistics (VERDICT r2 "weak" #2, next #3d) ----------------------------------------------------
+# The default product mode keeps 16 significant bits per operand.  Every other test feeds it U(+-1/sqrt(fan_in)) weights and
+# O(1) activations; a trained checkpoint has heavy-tailed weights, channels with |mean| >> std in front of the skip convs and
+# attention logits tens of units apart.  The per-op bar (max-norm relative error <= 5e-5 against fp64 of the SAME fp32 inputs)
+# must hold there too, or bf16x3 has no business being the default.
+def report(line):
+    """stdout + gpurun_out/parity_report.txt (merged back by gpurun)"""
+    import os
+    print(line)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _heavy(shape, gen):
+    """Student-t(3) samples (seeded): heavy tails, |x| up to tens of standard deviations."""
+    z = torch.randn(shape, generator=gen)
+    chi = torch.stack([torch.randn(shape, generator=gen) ** 2 for _ in range(3)]).sum(0)
+    return z / torch.sqrt(chi / 3.0)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+def test_split_gemm_heavy_tailed_weights_and_large_mean_activations(mode):
+    from audioldm2_amd import ops as o
+    prev = o.set_mma(mode)
+    try:
+        gen = torch.Generator().manual_seed(11)
+        M, K, N = 2048, 640, 384
+        w = _heavy((N, K), gen) / math.sqrt(K)                 # |w| up to ~30x its rms
+        x = torch.randn(1, M, K, generator=gen)
+        x[..., ::7] += 1.0e3                                    # every 7th channel: mean / std = 1e3
+        x[..., 3::11] *= 50.0                                   # outlier channels
+        b = torch.randn(N, generator=gen)
+        xs = o.split_rows(x.cuda())                             # the product path: pre-split operand, DMA-fed GEMM
+        y = o.linear(xs, o.pack_conv(w, b))
+        ref = x.double() @ w.double().t() + b.double()
+        err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+        report(f"stress GEMM heavy-tailed W, mean/std 1e3 channels ({mode}): max-norm rel err {err:.2e}")
+        assert err < 5e-5, err
+    finally:
+        o.set_mma(prev)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+def test_attention_sharp_logits(mode):
+    """Scores spread over +-30 (softmax close to one-hot with a few competing keys): the exponentials amplify any error of the
+    score products."""
+    from audioldm2_amd import ops as o
+    prev = o.set_mma(mode)
+    try:
+        gen = torch.Generator().manual_seed(5)
+        B, H, L = 2, 8, 512
+        q = torch.randn(B, L, H * 32, generator=gen) * 4.0
+        k = torch.randn(B, L, H * 32, generator=gen) * 4.0     # q.k / sqrt(32) ~ N(0, 16^2 / ...): |logit| reaches 30+
+        v = _heavy((B, L, H * 32), gen)
+        out = o.attention(q.cuda(), k.cuda(), v.cuda(), H).double().cpu()
+        sh = lambda t: t.double().view(B, L, H, 32).transpose(1, 2)
+        s = sh(q) @ sh(k).transpose(-1, -2) / math.sqrt(32)
+        assert float(s.abs().max()) > 30.0
+        ref = (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(B, L, H * 32)
+        err = float((out - ref).abs().max() / ref.abs().max())
+        report(f"stress attention |logit| up to {float(s.abs().max()):.0f} ({mode}): max-norm rel err {err:.2e}")
+        assert err < 5e-5, err
+    finally:
+        o.set_mma(prev)

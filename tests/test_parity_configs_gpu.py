@@ -35,14 +35,19 @@ def report(line):
         pass
 
 
-@pytest.mark.parametrize("model_name,fixture,keys_json", [
-    ("audioldm2-speech-gigaspeech", "e2e_speech_2step_b1", "e2espeech_statedict_keys.json"),
-    ("audioldm2-full-large-1150k", "e2e_large_2step_b1", "e2elarge_statedict_keys.json")])
-def test_e2e_speech_and_large_match_reference_generate_batch(model_name, fixture, keys_json):
-    """BASELINE configs 4 / 5 end to end against the REAL reference's generate_batch fixtures (B=1, 2 DDIM steps,
-    CFG 3.5, seed 42): the speech model's single 512-token context (masked cross attention over 512 keys) and the
-    large model's three context slots with transformer depth 2."""
+@pytest.mark.parametrize("model_name,fixture,keys_json,B,steps", [
+    ("audioldm2-speech-gigaspeech", "e2e_speech_2step_b1", "e2espeech_statedict_keys.json", 1, 2),
+    ("audioldm2-full-large-1150k", "e2e_large_2step_b1", "e2elarge_statedict_keys.json", 1, 2),
+    ("audioldm2-speech-gigaspeech", "e2e_speech_20step_b2", "e2espeech_statedict_keys.json", 2, 20),
+    ("audioldm2-full-large-1150k", "e2e_large_20step_b2", "e2elarge_statedict_keys.json", 2, 20)])
+def test_e2e_speech_and_large_match_reference_generate_batch(model_name, fixture, keys_json, B, steps):
+    """BASELINE configs 4 / 5 end to end against the REAL reference's generate_batch fixtures (B=1 at 2 DDIM steps and B=2 at
+    20 steps, CFG 3.5, seed 42): the speech model's single 512-token context (masked cross attention over 512 keys) and the
+    large model's three context slots with transformer depth 2.  Random-init weights; the waveform error is asserted against
+    the distance between two unrelated samples' waveforms (fixture `wave_between_rms`), not only against 1e-3."""
     from audioldm2_amd.pipeline import build_model, seed_everything
+    if not os.path.exists(os.path.join(GOLD, fixture + ".npz")):
+        pytest.skip(f"{fixture} absent")
     g = gold(fixture)
     m = build_model(model_name=model_name)
     with open(os.path.join(GOLD, keys_json)) as f:
@@ -60,15 +65,16 @@ def test_e2e_speech_and_large_match_reference_generate_batch(model_name, fixture
     m.decode_first_stage_cl = hook
     seed_everything(cases.E2E_SEED)
     m.latent_t_size = 256
-    wave = m.generate_batch(cases.e2e_batch(1), unconditional_guidance_scale=3.5, ddim_steps=2, n_gen=1, duration=10)
-    assert wave.shape == (1, 1, int(g["wave_len"]))
+    wave = m.generate_batch(cases.e2e_batch(B), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
+    assert wave.shape == (B, 1, int(g["wave_len"]))
     el = rms(rec["latent"].double().cpu().numpy() - g["latent"]) / rms(g["latent"])
     eh = rms(wave[..., :32768].astype(np.float64) - g["wave_head"])
     ed = rms(wave[..., ::16].astype(np.float64) - g["wave_dec"])
-    report(f"{model_name} e2e 2 steps B=1: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err "
-           f"{ed:.3e} / rms_ref {float(g['wave_rms']):.3e}")
+    between = float(g["wave_between_rms"])
+    report(f"{model_name} e2e {steps} steps B={B}: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err "
+           f"{ed:.3e} / rms_ref {float(g['wave_rms']):.3e} / between-sample {between:.3e}")
     assert el < 1e-4
-    assert max(eh, ed) < 1e-3 and max(eh, ed) / float(g["wave_rms"]) < 1e-3
+    assert between > 1e-2 and max(eh, ed) < 1e-3 and max(eh, ed) < 1e-3 * between
     del m
     torch.cuda.empty_cache()
 
