@@ -98,10 +98,54 @@ class FixedCond(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
-def default_audioldm_config(model_name: str = "audioldm2-full", t5_len: int = 32) -> dict:
+def hip_cond_stage_config(model_name: str = "audioldm2-full", t5_config: Optional[dict] = None,
+                          clap_config: Optional[dict] = None) -> dict:
+    """The reference's `cond_stage_config` (utils.py:127-187 speech, :354-411 full / large, :497-561 48k) with every `target`
+    pointing at the MI355X conditioners: same keys, same order, same params.  t5_config / clap_config: geometry overrides for
+    tests (a 3-layer T5, a 2-layer RoBERTa); None = flan-t5-large / roberta-base like the reference.  The tokenizers come
+    from the Hub in the reference (encoders/modules.py:126, :573); offline, set `.tokenizer` / `.tokenize` on the built
+    modules."""
+    M = "audioldm2_amd."
+    clap = {"cond_stage_key": "text", "conditioning_key": "film", "target": M + "clap.CLAPAudioEmbeddingClassifierFreev2",
+            "params": {"sampling_rate": 48000, "embed_mode": "text", "amodel": "HTSAT-base"}}
+    if clap_config is not None:
+        clap["params"].update({"config": clap_config, "audio_config": False})
+    t5 = {"cond_stage_key": "text", "conditioning_key": "crossattn", "target": M + "t5.FlanT5HiddenState"}
+    if t5_config is not None:
+        t5["params"] = {"config": t5_config}
+
+    def mae(pool):
+        return {"cond_stage_key": "ta_kaldi_fbank", "conditioning_key": "crossattn",
+                "target": M + "seqgen.AudioMAEConditionCTPoolRand",
+                "params": {"regularization": False, "no_audiomae_mask": True, "time_pooling_factors": [pool],
+                           "freq_pooling_factors": [pool], "eval_time_pooling": pool, "eval_freq_pooling": pool,
+                           "mask_ratio": 0}}
+
+    def seq(length, keys, dims, inner, prob):
+        return {"cond_stage_key": "all", "conditioning_key": "crossattn", "target": M + "seqgen.SequenceGenAudioMAECond",
+                "params": {"always_output_audiomae_gt": False, "learnable": True, "device": "cuda", "use_gt_mae_output": True,
+                           "use_gt_mae_prob": prob, "base_learning_rate": 0.0002, "sequence_gen_length": length,
+                           "use_warmup": True, "sequence_input_key": keys, "sequence_input_embed_dim": dims, "batchsize": 16,
+                           "cond_stage_config": inner}}
+    if "48k" in model_name:
+        return {"film_clap_cond1": copy.deepcopy(clap)}
+    if "-speech-" in model_name:
+        phon = {"cond_stage_key": "phoneme_idx", "conditioning_key": "crossattn", "target": M + "phoneme.PhonemeEncoder",
+                "params": {"vocabs_size": 183, "pad_token_id": 0, "pad_length": 310}}
+        inner = {"film_clap_cond1": copy.deepcopy(clap), "crossattn_vits_phoneme": phon, "crossattn_audiomae_pooled": mae(1)}
+        return {"crossattn_audiomae_generated": seq(512, ["film_clap_cond1", "crossattn_vits_phoneme"], [512, 192], inner, 1)}
+    inner = {"film_clap_cond1": copy.deepcopy(clap), "crossattn_flan_t5": copy.deepcopy(t5), "crossattn_audiomae_pooled": mae(8)}
+    return {"crossattn_audiomae_generated": seq(8, ["film_clap_cond1", "crossattn_flan_t5"], [512, 1024], inner, 0.0),
+            "crossattn_flan_t5": copy.deepcopy(t5)}
+
+
+def default_audioldm_config(model_name: str = "audioldm2-full", t5_len: int = 32, conditioners: str = "synthetic",
+                            t5_config: Optional[dict] = None, clap_config: Optional[dict] = None) -> dict:
     """Hot-path view of the reference's config dicts (utils.py:116-192, 221-411, 413-561): identical
-    `unet_config` / `first_stage_config` params, our `target`s, synthetic conditioners under the
-    reference's cond keys (same keys, same order)."""
+    `unet_config` / `first_stage_config` params, our `target`s, and under the reference's cond keys (same keys, same order)
+    either synthetic conditioners (`conditioners="synthetic"`: seeded contexts of the right shapes — bench.py, most tests)
+    or the real conditioner stack on the MI355X (`conditioners="hip"`: hip_cond_stage_config — SequenceGenAudioMAECond over
+    CLAP text + FLAN-T5 (+ phoneme encoder), FLAN-T5, CLAP; also builds the CLAP re-ranker like ddpm.py:114-120)."""
     unet = {"image_size": 64, "context_dim": [768, 1024], "in_channels": 8, "out_channels": 8,
             "model_channels": 128, "attention_resolutions": [8, 4, 2], "num_res_blocks": 2,
             "channel_mult": [1, 2, 3, 5], "num_head_channels": 32, "use_spatial_transformer": True,
@@ -146,6 +190,13 @@ def default_audioldm_config(model_name: str = "audioldm2-full", t5_len: int = 32
                                     "target": "audioldm2_amd.pipeline.FixedCond",
                                     "params": {"kind": "film", "dim": 512, "seed": 3}}}
         embed_dim = 16
+    if conditioners == "hip":
+        cond = hip_cond_stage_config(model_name, t5_config=t5_config, clap_config=clap_config)
+        params["build_clap"] = True
+        if clap_config is not None:
+            params["clap_config"] = {"config": clap_config}
+    else:
+        assert conditioners == "synthetic", conditioners
     params["unet_config"] = {"target": "audioldm2_amd.unet.UNetModel", "params": unet}
     params["first_stage_config"] = {
         "target": "audioldm2_amd.vae.AutoencoderKL",

@@ -252,10 +252,121 @@ class Sequence2AudioMAE(nn.Module):
         return toks, cond_dict
 
     # ---- conditioning through the sub-modules (sequence_input.py:327-370, 385-403) ---------------------------------
+    @staticmethod
+    def get_input_item(batch, k):
+        """sequence_input.py:327-350: the view of the batch a conditioner with `cond_stage_key` k receives."""
+        ret = {"fbank": batch["log_mel_spec"].unsqueeze(1).contiguous().float(), "stft": batch["stft"].contiguous().float(),
+               "waveform": batch["waveform"].contiguous().float(), "text": list(batch["text"]), "fname": batch["fname"]}
+        for key in batch.keys():
+            if key not in ret:
+                ret[key] = batch[key]
+        return ret[k]
+
     def get_input(self, batch) -> dict:
+        """sequence_input.py:352-370 at unconditional_cfg = False: every sub-conditioner on its view of the batch."""
         cond = {}
         for key, meta in self.cond_stage_model_metadata.items():
-            k = meta["cond_stage_key"]
-            xc = batch if k == "all" else batch[k]
+            xc = self.get_input_item(batch, meta["cond_stage_key"])
+            if torch.is_tensor(xc) and torch.cuda.is_available():
+                xc = xc.cuda()
             cond[key] = self.cond_stage_models[meta["model_idx"]](xc)
         return cond
+
+    def cfg_uncond(self, batch_size):
+        """sequence_input.py:85-98: the unconditional condition of every sub-conditioner; the (never generated) CLAP-to-AudioMAE
+        feature is the pooled AudioMAE one."""
+        uncond = {}
+        for key, meta in self.cond_stage_model_metadata.items():
+            uncond[key] = self.cond_stage_models[meta["model_idx"]].get_unconditional_condition(batch_size)
+        assert "crossattn_audiomae_pooled" in uncond, "The module is not initialized with AudioMAE"
+        uncond["crossattn_clap_to_audiomae_feature"] = uncond["crossattn_audiomae_pooled"]
+        return uncond
+
+
+class SequenceGenAudioMAECond(Sequence2AudioMAE):
+    """Drop-in for `audioldm2.latent_diffusion.modules.encoders.modules.SequenceGenAudioMAECond` (encoders/modules.py:201-300),
+    the `cond_stage_config` target of `crossattn_audiomae_generated` (utils.py:127, :354): same constructor keywords, same
+    state-dict keys (Sequence2AudioMAE's + `cond_stage_models.{i}.*` of the sub-conditioners), `forward(batch) -> dict` and
+    `get_unconditional_condition(batchsize) -> dict`, so the reference's LatentDiffusion wires it through the config string
+    alone.  At inference the reference always generates (the ground-truth AudioMAE branch is commented
+    out, encoders/modules.py:275-278)."""
+
+    def __init__(self, cond_stage_config, base_learning_rate, sequence_gen_length, sequence_input_key, sequence_input_embed_dim,
+                 batchsize, always_output_audiomae_gt=False, pretrained_path=None, force_reload_pretrain_avoid_overwrite=False,
+                 learnable=True, use_warmup=True, device=None, use_gt_mae_output=None, use_gt_mae_prob=None):
+        super().__init__(base_learning_rate=base_learning_rate, cond_stage_config=cond_stage_config,
+                         sequence_gen_length=sequence_gen_length, sequence_input_key=sequence_input_key,
+                         sequence_input_embed_dim=sequence_input_embed_dim, use_warmup=False, batchsize=batchsize)
+        assert use_gt_mae_output is not None and use_gt_mae_prob is not None
+        self.always_output_audiomae_gt = always_output_audiomae_gt
+        self.force_reload_pretrain_avoid_overwrite = force_reload_pretrain_avoid_overwrite
+        self.pretrained_path = pretrained_path
+        self.device = device
+        self.is_reload = not force_reload_pretrain_avoid_overwrite
+        self.load_pretrain_model()
+        self.use_gt_mae_output, self.use_gt_mae_prob, self.learnable = use_gt_mae_output, use_gt_mae_prob, learnable
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+        for p in self.parameters():   # sampling only: nothing here trains
+            p.requires_grad = False
+        self.eval()
+
+    def load_pretrain_model(self):
+        """encoders/modules.py:258-262"""
+        if self.pretrained_path is not None:
+            print("Reload SequenceGenAudioMAECond from %s" % self.pretrained_path)
+            self.load_state_dict(torch.load(self.pretrained_path)["state_dict"])
+            self.invalidate_packed()
+
+    def get_unconditional_condition(self, batchsize):
+        """encoders/modules.py:265-271: a DICT — DiffusionWrapper.route takes its last crossattn entry, the zero tokens."""
+        ret = self.cfg_uncond(batchsize)
+        pooled = ret["crossattn_audiomae_pooled"]
+        ret["crossattn_audiomae_generated"] = [pooled[0], torch.ones_like(pooled[1]).float()]
+        return ret
+
+    @torch.no_grad()
+    def forward(self, batch):
+        """encoders/modules.py:273-300: generate the AudioMAE tokens from the batch's text conditions; the sub-conditioners'
+        outputs ride along under their own keys (LatentDiffusion keeps the ones that are its cond keys, e.g. nothing else
+        for audioldm2-full — its own `crossattn_flan_t5` model runs again, like the reference's)."""
+        if self.force_reload_pretrain_avoid_overwrite and not self.is_reload:
+            self.load_pretrain_model()
+            self.is_reload = True
+        tokens, cond_dict = self.generate(batch)
+        mask = torch.ones((tokens.size(0), tokens.size(1)), device=tokens.device).float()
+        ret = {"crossattn_audiomae_generated": [tokens, mask]}
+        for key in cond_dict.keys():
+            ret[key] = cond_dict[key]
+        return ret
+
+
+class AudioMAEConditionCTPoolRand(nn.Module):
+    """Sampling-path stand-in for `encoders/modules.py:427-546` (AudioMAE ViT + pooling).  On the sampling path this conditioner
+    contributes exactly two things, both reproduced here: (1) `get_unconditional_condition` — zero tokens + a ones mask of
+    512 / (eval_time_pooling * eval_freq_pooling) positions (encoders/modules.py:465-479), which SequenceGenAudioMAECond
+    turns into the unconditional `crossattn_audiomae_generated`; (2) a `crossattn_audiomae_pooled` entry in the dict
+    `SequenceGenAudioMAECond.forward` returns — computed by the reference from `ta_kaldi_fbank` (all zeros in
+    `make_batch_for_text_to_audio`, pipeline.py:116) and consumed by NOBODY at inference: it is neither a sequence input key
+    of the generator nor a cond key of LatentDiffusion (utils.py:354-411).  forward() therefore returns tokens of the right
+    shape without running a ViT (the reference needs `timm` for it; out of the hot path, SURVEY §2 OUT-OF-SCOPE).  The
+    checkpoint's `audiomae.*` tensors have no home here and are reported as unused by load_reference_state_dict."""
+
+    def __init__(self, time_pooling_factors=(1, 2, 4, 8), freq_pooling_factors=(1, 2, 4, 8), eval_time_pooling=None,
+                 eval_freq_pooling=None, mask_ratio=0.0, regularization=False, no_audiomae_mask=True,
+                 no_audiomae_average=False):
+        super().__init__()
+        self.eval_time_pooling, self.eval_freq_pooling = eval_time_pooling, eval_freq_pooling
+        self.time_pooling_factors, self.freq_pooling_factors = list(time_pooling_factors), list(freq_pooling_factors)
+        self.mask_ratio, self.use_reg = mask_ratio, regularization
+        self.no_audiomae_mask, self.no_audiomae_average = no_audiomae_mask, no_audiomae_average
+
+    def _tokens(self, batchsize):
+        token_num = int(512 / (min(self.eval_time_pooling, 64) * min(self.eval_freq_pooling, 8)))
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        return [torch.zeros((batchsize, token_num, 768), device=dev), torch.ones((batchsize, token_num), device=dev)]
+
+    def get_unconditional_condition(self, batchsize):
+        return self._tokens(batchsize)
+
+    def forward(self, batch):
+        return self._tokens(batch.shape[0])

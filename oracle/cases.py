@@ -279,3 +279,68 @@ def clap_waveform(B: int = 2, seed: int = 21) -> torch.Tensor:
         x = x + 0.1 * torch.randn(t.shape, generator=g) * (torch.sin(2 * math.pi * 0.7 * t + b) > 0)
         rows.append(x)
     return torch.stack(rows).float()
+
+
+# ---- conditioner drop-in end to end: stub tokenizers shared by the reference-side fixture generator and
+# the HIP-side test (the Hub tokenizers are unreachable offline: parity starts at "the same token ids on both sides") --------
+class StubT5Tokenizer:
+    """Stands in for AutoTokenizer.from_pretrained("google/flan-t5-large") as FlanT5HiddenState calls it (encoders/modules.py:
+    175-181: padding=True, truncation, return_tensors="pt"): deterministic ids from the characters of each prompt, EOS (1)
+    last, right padded with 0 to the longest prompt; "" -> EOS alone.  Ids < 512 (cases.t5_test_config's vocabulary)."""
+
+    def __call__(self, prompt, max_length=128, padding=True, truncation=True, return_tensors="pt"):
+        import types
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        rows = [[3 + (ord(ch) * 11 + i) % 500 for i, ch in enumerate(s)][: max_length - 1] + [1] for s in prompt]
+        T = max(len(r) for r in rows)
+        ids = torch.zeros(len(rows), T, dtype=torch.long)
+        mask = torch.zeros(len(rows), T, dtype=torch.long)
+        for b, r in enumerate(rows):
+            ids[b, : len(r)] = torch.tensor(r)
+            mask[b, : len(r)] = 1
+        return types.SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+
+class StubRobertaTokenizer:
+    """Stands in for RobertaTokenizer.from_pretrained("roberta-base") as CLAP calls it (encoders/modules.py:737-745:
+    padding="max_length"): <s> = 0 first, </s> = 2 last, pad = 1, padded to 64; ids < 600 (cases.clap_text_test_config)."""
+
+    def __call__(self, texts, padding=None, truncation=None, max_length=None, return_tensors=None):
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        T = 64
+        ids = torch.ones(len(texts), T, dtype=torch.long)
+        mask = torch.zeros(len(texts), T, dtype=torch.long)
+        for b, s in enumerate(texts):
+            row = [0] + [3 + (ord(ch) * 7 + i) % 500 for i, ch in enumerate(s)][: T - 2] + [2]
+            ids[b, : len(row)] = torch.tensor(row)
+            mask[b, : len(row)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+E2E_COND_PROMPTS = ["a dog barking in the rain", "slow piano melody with soft strings"]
+
+
+def e2e_cond_batch():
+    b = e2e_batch(len(E2E_COND_PROMPTS))
+    b["text"] = list(E2E_COND_PROMPTS)
+    b["fname"] = [t.replace(" ", "_") for t in b["text"]]
+    return b
+
+
+def cond_state_dict(shapes: dict, seed: int = 0) -> dict:
+    """Deterministic weights for the conditioner stack under `cond_stage_models.*`: name-keyed like everything else, with
+    t5_state_dict's scalings for the tensors of the T5 encoders (q without 1/sqrt(d), relative-position biases, embeddings)."""
+    import math
+    from . import weights
+    sd = weights.make_state_dict(shapes, seed=seed)
+    for k, v in list(sd.items()):
+        if k.endswith("SelfAttention.q.weight"):
+            sd[k] = v * (64 ** -0.5) * 3.0
+        elif "relative_attention_bias" in k:
+            sd[k] = v * math.sqrt(v.shape[1]) * 0.8
+        elif k.endswith(("shared.weight", "encoder.embed_tokens.weight")):
+            sd[k] = v * math.sqrt(v.shape[1])
+    for k in list(sd):
+        if k.endswith("encoder.embed_tokens.weight"):
+            sd[k] = sd[k[: -len("encoder.embed_tokens.weight")] + "shared.weight"]
+    return sd

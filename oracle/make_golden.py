@@ -414,6 +414,62 @@ def gen_htsat():
         json.dump({k: list(v) for k, v in shapes.items()}, f)
 
 
+def gen_e2e_cond(steps: int, name: str):
+    """the path prompts -> conditioners -> sampler -> waveform as ONE job of the REAL reference classes —
+    `LatentDiffusion.generate_batch` (ddpm.py:1477) with `cond_stage_config` = audioldm2-full's (utils.py:354-411):
+    SequenceGenAudioMAECond (real) over CLAP text (oracle/refcond.RefClapText), FlanT5HiddenState (real, 3 layers) and the
+    AudioMAE stand-in, plus the outer FlanT5HiddenState.  Two different prompts, CFG 3.5, seed 42."""
+    from oracle import refcond
+    refcond.encoders_modules()
+    import audioldm2.utils as ru
+    from audioldm2.latent_diffusion.models.ddpm import LatentDiffusion
+    P = ru.default_audioldm_config("audioldm2-full")["model"]["params"]
+    P["cond_stage_config"] = refcond.cond_stage_config()
+    P["device"] = "cpu"
+    torch.manual_seed(0)
+    ld = LatentDiffusion(**P).eval()
+    sd = ld.state_dict()
+    hot = {k: tuple(v.shape) for k, v in sd.items()
+           if k.startswith("model.diffusion_model.") or k.startswith("first_stage_model.")}
+    cond = {k: tuple(v.shape) for k, v in sd.items() if k.startswith("cond_stage_models.") and v.is_floating_point()
+            and not k.endswith("model.wte.weight")}   # GPT-2's token table is never used (inputs_embeds)
+    new = weights.make_state_dict(hot, seed=0)
+    new.update(cases.cond_state_dict(cond, seed=0))
+    new["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    missing, unexpected = ld.load_state_dict(new, strict=False)
+    assert not unexpected, unexpected
+    with open(os.path.join(OUT, "e2econd_statedict_keys.json"), "w") as f:
+        json.dump({"hot": {k: list(v) for k, v in hot.items()}, "cond": {k: list(v) for k, v in cond.items()}}, f)
+    ld.latent_t_size = 256
+    rec = {}
+    orig_decode = ld.decode_first_stage
+    seq = ld.cond_stage_models[0]
+    orig_forward = seq.forward
+
+    def decode_hook(z):
+        rec["latent"] = z.clone()
+        return orig_decode(z)
+
+    def forward_hook(batch):
+        ret = orig_forward(batch)
+        rec["tokens"] = ret["crossattn_audiomae_generated"][0].clone()
+        rec["clap"] = ret["film_clap_cond1"].clone()
+        rec["t5"], rec["t5_mask"] = ret["crossattn_flan_t5"][0].clone(), ret["crossattn_flan_t5"][1].clone()
+        return ret
+    ld.decode_first_stage = decode_hook
+    seq.forward = forward_hook
+    _seed_all()
+    t0 = time.time()
+    wav = ld.generate_batch(cases.e2e_cond_batch(), unconditional_guidance_scale=3.5, ddim_steps=steps, n_gen=1, duration=10)
+    print(f"{name}: reference generate_batch with the real conditioner stack, B={wav.shape[0]} steps={steps}: {time.time()-t0:.1f}s "
+          f"wave rms {rms64(wav):.4f} tokens std {rec['tokens'].std():.3f} latent std {rec['latent'].std():.3f}")
+    ld.decode_first_stage = orig_decode
+    btw = between_sample_rms(ld, wav, rec["latent"])
+    save(name, latent=rec["latent"], tokens=rec["tokens"], clap=rec["clap"], t5=rec["t5"], t5_mask=rec["t5_mask"],
+         wave_head=wav[..., :32768], wave_dec=wav[..., ::16], wave_len=np.int64(wav.shape[-1]), wave_rms=np.float64(rms64(wav)),
+         wave_between_rms=np.float64(btw))
+
+
 def _seed_all():
     import random
     random.seed(cases.E2E_SEED)
@@ -514,5 +570,7 @@ if __name__ == "__main__":
         gen_e2e_named("audioldm2-speech-gigaspeech", 20, 2, "e2e_speech_20step_b2", "e2espeech_statedict_keys.json")
     if "all" in what or "e2elarge20" in what:
         gen_e2e_named("audioldm2-full-large-1150k", 20, 2, "e2e_large_20step_b2", "e2elarge_statedict_keys.json")
+    if "all" in what or "e2econd" in what:
+        gen_e2e_cond(4, "e2e_cond_4step_b2")
     if "e2e200" in what:
         gen_e2e(200, 1, "e2e_full_200step_b1")

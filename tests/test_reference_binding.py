@@ -126,3 +126,114 @@ def test_ddim_sampler_two_pass_cfg_fallback_matches_reference_fixture_and_batche
     print(f"two-pass CFG fallback: latent rel rms vs reference {e_ref:.2e}, vs batched path {e_bat:.2e}")
     assert e_ref < 1e-4   # same bar as test_e2e_5step_matches_reference_generate_batch
     assert e_bat < 1e-5
+
+
+# ---- the conditioner drop-in (VERDICT r2 "missing" #1 / next #4) ------------------------------------------------------------
+def _cond_keys():
+    with open(os.path.join(GOLD, "e2econd_statedict_keys.json")) as f:
+        k = json.load(f)
+    return {a: tuple(b) for a, b in k["hot"].items()}, {a: tuple(b) for a, b in k["cond"].items()}
+
+
+@pytest.mark.skipif(not refimport.available(), reason="needs the reference checkout (build container only)")
+def test_real_reference_latent_diffusion_builds_the_hip_conditioner_stack_from_config_strings():
+    """The reference's LatentDiffusion (ddpm.py:640) + its instantiate_from_config (utils.py:95-114) build OUR conditioners
+    from `cond_stage_config` target strings alone — `SequenceGenAudioMAECond` (the actual target of
+    `crossattn_audiomae_generated`, utils.py:354) over CLAP text + FLAN-T5 + the AudioMAE stand-in, and the outer FLAN-T5 —
+    and their state-dict keys are exactly the ones the real reference classes hold (fixture e2econd_statedict_keys.json,
+    written by oracle/make_golden.py from the REAL SequenceGenAudioMAECond / FlanT5HiddenState)."""
+    refimport.install()
+    import audioldm2.latent_diffusion.models.ddpm as rddpm
+    import audioldm2.utils as ru
+
+    import audioldm2_amd.clap as aclap
+    import audioldm2_amd.seqgen as aseq
+    import audioldm2_amd.t5 as at5
+    from audioldm2_amd.pipeline import hip_cond_stage_config
+    P = ru.default_audioldm_config("audioldm2-full")["model"]["params"]
+    ref_cond = P["cond_stage_config"]
+    ours = hip_cond_stage_config("audioldm2-full", t5_config=cases.t5_test_config(), clap_config=cases.clap_text_test_config())
+    # same keys, same order, same routing keys and the same params for the generator as the reference's own config
+    assert list(ours) == list(ref_cond)
+    for k in ours:
+        assert ours[k]["cond_stage_key"] == ref_cond[k]["cond_stage_key"]
+        assert ours[k]["conditioning_key"] == ref_cond[k]["conditioning_key"]
+    rp, op = ref_cond["crossattn_audiomae_generated"]["params"], ours["crossattn_audiomae_generated"]["params"]
+    assert {k: v for k, v in rp.items() if k != "cond_stage_config"} == {k: v for k, v in op.items() if k != "cond_stage_config"}
+    assert list(rp["cond_stage_config"]) == list(op["cond_stage_config"])
+    P["unet_config"]["target"] = "audioldm2_amd.unet.UNetModel"
+    P["first_stage_config"]["target"] = "audioldm2_amd.vae.AutoencoderKL"
+    P["cond_stage_config"] = ours
+    P["device"] = "cpu"
+    torch.manual_seed(0)
+    ld = rddpm.LatentDiffusion(**P).eval()
+    seq = ld.cond_stage_models[0]
+    assert isinstance(seq, aseq.SequenceGenAudioMAECond) and isinstance(ld.cond_stage_models[1], at5.FlanT5HiddenState)
+    assert isinstance(seq.cond_stage_models[0], aclap.CLAPAudioEmbeddingClassifierFreev2)
+    assert isinstance(seq.cond_stage_models[1], at5.FlanT5HiddenState)
+    assert isinstance(seq.cond_stage_models[2], aseq.AudioMAEConditionCTPoolRand)
+    assert ld.cond_stage_model_metadata["crossattn_audiomae_generated"]["cond_stage_key"] == "all"
+    if os.path.exists(os.path.join(GOLD, "e2econd_statedict_keys.json")):
+        _, cond = _cond_keys()
+        mine = {k: tuple(v.shape) for k, v in ld.state_dict().items() if k.startswith("cond_stage_models.")}
+        missing = [k for k in cond if k not in mine]
+        assert not missing, missing[:5]
+        assert all(mine[k] == cond[k] for k in cond)
+    # the unconditional condition is the reference's dict (encoders/modules.py:265-271); route() takes its LAST crossattn entry
+    # (CPU tensors are fine here: no kernel runs)
+    seq.cond_stage_models[2].get_unconditional_condition(2)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "e2e_cond_4step_b2.npz")), reason="conditioner e2e fixture absent")
+def test_prompts_to_waveform_through_the_hip_conditioner_stack():
+    """prompts -> (stub tokenizers) -> CLAP text + FLAN-T5 -> GPT-2 sequence generator -> DDIM -> VAE -> HiFi-GAN as ONE job of
+    `default_audioldm_config(conditioners="hip")`, against the same job run by the REAL reference LatentDiffusion over the REAL
+    SequenceGenAudioMAECond / FlanT5HiddenState (fixture e2e_cond_4step_b2: two prompts, 4 DDIM steps, CFG 3.5, seed 42;
+    random-init weights; T5 with 3 of 24 layers, RoBERTa with 2 of 12)."""
+    from audioldm2_amd.pipeline import LatentDiffusion, default_audioldm_config, seed_everything
+    g = np.load(os.path.join(GOLD, "e2e_cond_4step_b2.npz"))
+    hot, cond = _cond_keys()
+    cfg = default_audioldm_config("audioldm2-full", conditioners="hip", t5_config=cases.t5_test_config(),
+                                  clap_config=cases.clap_text_test_config())
+    cfg["model"]["params"]["build_clap"] = False    # one candidate per prompt: no re-ranker needed
+    torch.manual_seed(0)
+    ld = LatentDiffusion(**cfg["model"]["params"]).eval()
+    sd = weights.make_state_dict(hot, seed=0)
+    sd.update(cases.cond_state_dict(cond, seed=0))
+    sd["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    res = ld.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:5]
+    ld = ld.cuda()
+    seq = ld.cond_stage_models[0]
+    seq.cond_stage_models[0].tokenize = cases.StubRobertaTokenizer()
+    seq.cond_stage_models[1].tokenizer = cases.StubT5Tokenizer()
+    ld.cond_stage_models[1].tokenizer = cases.StubT5Tokenizer()
+    rec = {}
+    orig_fwd, orig_dec = seq.forward, ld.decode_first_stage_cl
+
+    def fwd(batch):
+        ret = orig_fwd(batch)
+        rec["tokens"], rec["clap"], rec["t5"] = ret["crossattn_audiomae_generated"][0], ret["film_clap_cond1"], ret["crossattn_flan_t5"][0]
+        return ret
+
+    def dec(z):
+        rec["latent"] = z.clone()
+        return orig_dec(z)
+    seq.forward, ld.decode_first_stage_cl = fwd, dec
+    seed_everything(cases.E2E_SEED)
+    ld.latent_t_size = 256
+    wave = ld.generate_batch(cases.e2e_cond_batch(), unconditional_guidance_scale=3.5, ddim_steps=4, n_gen=1, duration=10)
+    assert wave.shape == (2, 1, int(g["wave_len"]))
+    rel = lambda a, b: _rms(np.asarray(a, dtype=np.float64) - b) / _rms(b)
+    e_clap = rel(rec["clap"].double().cpu().numpy(), g["clap"])
+    e_t5 = rel(rec["t5"].double().cpu().numpy(), g["t5"])
+    e_tok = rel(rec["tokens"].double().cpu().numpy(), g["tokens"])
+    e_lat = rel(rec["latent"].double().cpu().numpy(), g["latent"])
+    eh = _rms(wave[..., :32768].astype(np.float64) - g["wave_head"])
+    ed = _rms(wave[..., ::16].astype(np.float64) - g["wave_dec"])
+    print(f"conditioner e2e: clap {e_clap:.2e}  t5 {e_t5:.2e}  generated tokens {e_tok:.2e}  latent {e_lat:.2e}  wave rms_err "
+          f"{max(eh, ed):.3e} / between-sample {float(g['wave_between_rms']):.3e}")
+    assert e_clap < 2e-4 and e_t5 < 2e-4 and e_tok < 5e-4
+    assert e_lat < 2e-4
+    assert max(eh, ed) < 1e-3 and max(eh, ed) < 1e-3 * float(g["wave_between_rms"])
