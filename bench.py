@@ -356,10 +356,13 @@ def main():
         wav = job()
     fence()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)          # per-rank wall time of the same K jobs: the skew is reported
+        per_rank = [round(float(t.item()), 4) for t in every]
+        dt = max(per_rank)                                 # contract: MAX over ranks
     assert wav.shape[:2] == (B, 1) and np.isfinite(wav).all()
     audio_seconds = wav.shape[-1] / float(ld.sampling_rate)  # delivered audio per prompt (10.24 s)
     khz = ld.sampling_rate // 1000
@@ -398,6 +401,9 @@ def main():
                        "global_batch": gB, "parallelism": f"prompt-sharded replicas x{world}",
                        "weight_broadcast_bytes": bcast_bytes},
         }
+        if per_rank is not None:
+            out["per_rank_seconds"] = per_rank
+            out["rank_skew_pct"] = round(100.0 * (max(per_rank) - min(per_rank)) / max(per_rank), 2)
         try:
             if args.no_step_probe:
                 raise RuntimeError("skipped (--no-step-probe)")
