@@ -74,7 +74,13 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) outp[o + j] = r[j];
     }
-    if (d.out_split) split_store4(d.out_split, orow, d.out_split_c, n, r, d.split_parts);
+    if (d.out_split) {
+        if (d.out_split_act == ALDM_ACT_LRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = r[j] > 0.0f ? r[j] : r[j] * d.out_split_slope;
+        }
+        split_store4(d.out_split, orow, d.out_split_c, n, r, d.split_parts);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,7 +246,7 @@ static bool dma_ws_eligible(const IgemmK& p, int BM, int BN) {
     const aldm_igemm_desc& d = p.d;
     const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (d.out_mul > 0 || d.accumulate || d.batch != 1 || d.act != ALDM_ACT_NONE) return false;
+    if (d.out_mul > 0 || d.accumulate || d.batch != 1 || d.act != ALDM_ACT_NONE || d.out_split_act != ALDM_ACT_NONE) return false;
     if (p.M % BM != 0 || d.N % BN != 0 || (d.N & 3) != 0 || (d.ldo & 3) != 0) return false;
     if (!al16(d.out) || !al16(d.res) || !al16(d.bias) || !al16(d.rowbias) || !al16(d.out_split)) return false;
     if (d.rowbias && (p.OHW % BM != 0 || (p.rb_ld & 3) != 0)) return false;
@@ -335,6 +341,9 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     p.nst = 0;
     p.ws = 0;
     p.ws_blocks = 0;
+    ALDM_CHECK(d.out_split_act == ALDM_ACT_NONE || (d.out_split_act == ALDM_ACT_LRELU && d.out_split != nullptr &&
+                                                   d.epi_mode == ALDM_EPI_PLAIN),
+               "aldm_igemm: out_split_act must be ALDM_ACT_NONE or ALDM_ACT_LRELU with a split-image output of the plain epilogue");
     if (d.out_split) {
         ALDM_CHECK(d.out_split_c > 0 && d.out_split_c % 32 == 0 && d.out_split_c >= (geglu ? d.N / 2 : d.N) &&
                        d.N % 4 == 0 && d.batch == 1 && (reinterpret_cast<uintptr_t>(d.out_split) & 15) == 0 &&

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                                                          int C1, int C2, int64_t rows, int P,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, char* __restrict__ dst,
-                                                         char* __restrict__ dst_raw, int parts) {
+                                                         char* __restrict__ dst_raw, int parts, float slope) {
     const int C = C1 + C2;
     const int C8 = C >> 3;
     const int64_t total = rows * C8;
@@ -97,6 +97,13 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                 v1[e] = silu_fast(v1[e]);
             }
         }
+        if constexpr (ACT == ALDM_ACT_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = v0[e] > 0.0f ? v0[e] : v0[e] * slope;
+                v1[e] = v1[e] > 0.0f ? v1[e] : v1[e] * slope;
+            }
+        }
         split4_parts(v0, p0, parts);
         split4_parts(v1, p1, parts);
 #pragma unroll
@@ -111,15 +118,25 @@ using namespace aldm;
 
 extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C, int parts) { return rows * (int64_t)(C / 32) * 64 * parts; }
 
+extern "C" int aldm_split_rows_act(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                                   const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, void* stream);
+
 extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                                const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream) {
+    ALDM_CHECK(act == ALDM_ACT_NONE || act == ALDM_ACT_SILU, "aldm_split_rows: activation %d not supported", act);
+    return aldm_split_rows_act(x1, x2, C1, C2, rows, P, scale, shift, act, 0.f, dst, dst_raw, parts, stream);
+}
+
+extern "C" int aldm_split_rows_act(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                                   const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, void* stream) {
     if (!x2) C2 = 0;
     const int C = C1 + C2;
     ALDM_CHECK(x1 && dst && rows > 0 && P > 0 && (parts == 2 || parts == 3), "aldm_split_rows: bad args");
     ALDM_CHECK(C % 32 == 0 && C1 % 8 == 0 && C2 % 8 == 0, "aldm_split_rows: need (C1+C2) %% 32 == 0, C1 %% 8 == 0 (C1=%d C2=%d)",
                C1, C2);
     ALDM_CHECK((scale == nullptr) == (shift == nullptr), "aldm_split_rows: scale/shift must come together");
-    ALDM_CHECK(act == ALDM_ACT_NONE || act == ALDM_ACT_SILU, "aldm_split_rows: activation %d not supported", act);
+    ALDM_CHECK(act == ALDM_ACT_NONE || act == ALDM_ACT_SILU || act == ALDM_ACT_LRELU, "aldm_split_rows: activation %d not supported",
+               act);
     ALDM_CHECK(((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(dst) |
                  reinterpret_cast<uintptr_t>(dst_raw) | reinterpret_cast<uintptr_t>(scale) |
                  reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
@@ -129,12 +146,14 @@ extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2,
     hipStream_t st = (hipStream_t)stream;
 #define ALDM_SPLIT(A_, F_)                                                                                        \
     hipLaunchKernelGGL((split_rows_kernel<A_, F_>), dim3(blocks), dim3(256), 0, st, x1, x2, C1, C2, rows, P, scale, \
-                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw), parts)
+                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw), parts, slope)
     if (scale) {
         if (act == ALDM_ACT_SILU) ALDM_SPLIT(ALDM_ACT_SILU, true);
+        else if (act == ALDM_ACT_LRELU) ALDM_SPLIT(ALDM_ACT_LRELU, true);
         else ALDM_SPLIT(ALDM_ACT_NONE, true);
     } else {
         if (act == ALDM_ACT_SILU) ALDM_SPLIT(ALDM_ACT_SILU, false);
+        else if (act == ALDM_ACT_LRELU) ALDM_SPLIT(ALDM_ACT_LRELU, false);
         else ALDM_SPLIT(ALDM_ACT_NONE, false);
     }
 #undef ALDM_SPLIT

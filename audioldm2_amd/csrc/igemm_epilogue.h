@@ -281,6 +281,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                     if ((okmask >> it) & 1u) *reinterpret_cast<f32x4*>(outp + rowoff[it]) = v[it];
             }
             if (simg) {  // second output: the result as a split image (host checks N % 4 == 0, vec)
+                if (d.out_split_act == ALDM_ACT_LRELU) {   // ... of leaky_relu(result): the next conv's pre-activated operand
+#pragma unroll
+                    for (int it = 0; it < ITC; ++it)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[it][c] = v[it][c] > 0.0f ? v[it][c] : v[it][c] * d.out_split_slope;
+                }
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
                     if ((okmask >> it) & 1u) split_store4(simg, srow[it], d.out_split_c, ncol, v[it], d.split_parts);

@@ -111,6 +111,10 @@ class Generator(nn.Module):
         x = ops.conv(mel_cl.reshape(B, 1, T, Cm), pk["pre"], pad=(0, 3))
         nk = self.num_kernels
         for i, (u, k) in enumerate(zip(self.h.upsample_rates, self.h.upsample_kernel_sizes)):
+            if ops.use_dma() and x.shape[-1] % 32 == 0 and pk["ups"][i][0].N >= self.DMA_MIN_CHANNELS \
+                    and pk["ups"][i][0].N % 32 == 0:
+                x = self._stage_dma(pk, i, u, k, x)
+                continue
             # x = ups[i](leaky_relu(x, 0.1))   models.py:151-152
             p = (k - u) // 2
             L = x.shape[2]
@@ -144,6 +148,48 @@ class Generator(nn.Module):
         # x = tanh(conv_post(leaky_relu(x)))  (default slope 0.01, models.py:161-163)
         y = ops.conv(x, pk["post"], pad=(0, 3), pre_act=ACT_LRELU, pre_slope=0.01, act=ACT_TANH)
         return y.view(B, 1, -1)
+
+    # Stages with at least this many output channels run on the DMA-fed GEMM over pre-split operands (round 3): they hold
+    # 87 % of the vocoder's FLOPs (L * C^2 per stage: 1.34, 1.34, 0.67, 0.34, 0.17 G for the 16 kHz generator) and are matrix-pipe
+    # bound; the 64- / 32-channel stages are HBM bound (K = 3 * C is short) and an extra operand-image pass would cost more
+    # than the faster products give back.
+    DMA_MIN_CHANNELS = 128
+
+    def _stage_dma(self, pk, i, u, k, x):
+        """One upsampling stage with every leaky_relu applied by the PRODUCER of the conv's operand image instead of the conv's
+        gather: split_rows(leaky_relu(x)) in front of the polyphase transposed conv and of the three ResBlocks (one image
+        shared by all of them), conv1's epilogue (activation, split image only), conv2's epilogue (fp32 running sum +
+        split(leaky_relu(sum)) for the next conv1: out_split_act).  Same arithmetic as the register-staged stage."""
+        B = x.shape[0]
+        nk = self.num_kernels
+        p = (k - u) // 2
+        L = x.shape[2]
+        Lout = (L - 1) * u - 2 * p + k
+        phases = pk["ups"][i]
+        Tt = phases[0].KW
+        y = torch.empty((B, 1, Lout, phases[0].N), device=x.device, dtype=torch.float32)
+        Q = (Lout + p) // u + 2
+        xa = ops.split_rows(x, act=ACT_LRELU, slope=LRELU_SLOPE)
+        for ph in range(u):
+            ops.conv(xa, phases[ph], pad=(0, Tt - 1), out_hw=(1, Q), out=y, remap=(u, ph - p, Lout))
+        x = y
+        xl = ops.split_rows(x, act=ACT_LRELU, slope=LRELU_SLOPE)
+        xs = torch.empty_like(x)
+        for j in range(nk):
+            rb = self.resblocks[i * nk + j]
+            c1s, c2s = pk["res"][i * nk + j]
+            kk = rb.kernel_size
+            r, rl = x, xl
+            nd = len(rb.dilation)
+            for m, d in enumerate(rb.dilation):
+                t1 = ops.conv(rl, c1s[m], pad=(0, _get_padding(kk, d)), dil=(1, d), act=ACT_LRELU, act_slope=LRELU_SLOPE,
+                              split_out="only")
+                if m < nd - 1:
+                    r, rl = ops.conv(t1, c2s[m], pad=(0, _get_padding(kk, 1)), res=r, split_out="also", split_act=ACT_LRELU,
+                                     split_slope=LRELU_SLOPE)
+                else:
+                    ops.conv(t1, c2s[m], pad=(0, _get_padding(kk, 1)), res=r, alpha=1.0 / nk, out=xs, accumulate=(j > 0))
+        return xs
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -46,6 +46,7 @@ class IgemmDesc(C.Structure):
         ("hint_bm", C.c_int32), ("hint_bn", C.c_int32), ("hint_splits", C.c_int32), ("hint_kgroups", C.c_int32),
         ("w_split", C.c_void_p), ("hint_mma", C.c_int32), ("hint_stages", C.c_int32),
         ("a_split", C.c_void_p), ("out_split", C.c_void_p), ("out_split_c", C.c_int32), ("split_parts", C.c_int32),
+        ("out_split_act", C.c_int32), ("out_split_slope", C.c_float),
     ]
 
 
@@ -64,6 +65,8 @@ _SIGS = {
     "aldm_split_image_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "aldm_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_split_rows_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_layernorm_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_float, C.c_int, C.c_void_p]),
     "aldm_attention_d32_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -182,9 +182,9 @@ def use_dma() -> bool:
 
 
 def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act: int = ACT_NONE,
-               want_raw: bool = False):
+               want_raw: bool = False, slope: float = 0.0):
     """split(act(x*scale + shift)) of channels-last x (++ x2 along C) -> SplitT; pre = (scale, shift) each [B, C]
-    (GroupNorm apply, from gn_stats).  want_raw: also return split(x ++ x2)."""
+    (GroupNorm apply, from gn_stats); act: ACT_NONE | ACT_SILU | ACT_LRELU(slope).  want_raw: also return split(x ++ x2)."""
     _chk(x, "split_rows.x")
     C1 = x.shape[-1]
     C2 = 0
@@ -201,8 +201,8 @@ def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act
     if pre is not None:
         sc, sh = pre
         assert sc.shape == (x.shape[0], C1 + C2) and sc.is_contiguous() and sh.is_contiguous()
-    _l.check(_l.load().aldm_split_rows(x.data_ptr(), _p(x2), C1, C2, rows, P, _p(sc), _p(sh), act, dst.data_ptr(),
-                                       None if raw is None else raw.data_ptr(), dst.parts, _stream()), "split_rows")
+    _l.check(_l.load().aldm_split_rows_act(x.data_ptr(), _p(x2), C1, C2, rows, P, _p(sc), _p(sh), act, slope, dst.data_ptr(),
+                                           None if raw is None else raw.data_ptr(), dst.parts, _stream()), "split_rows")
     return (dst, raw) if want_raw else dst
 
 
@@ -471,7 +471,7 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
          act: int = ACT_NONE, act_slope: float = 0.0, alpha: float = 1.0,
          out: Optional[torch.Tensor] = None, accumulate: bool = False,
          remap: Optional[Tuple[int, int, int]] = None,
-         use_pw_bias: bool = True, split_out: Optional[str] = None):
+         use_pw_bias: bool = True, split_out: Optional[str] = None, split_act: int = ACT_NONE, split_slope: float = 0.0):
     """Implicit-GEMM convolution (aldm_igemm).  x: [B, H, W, C1] (+ x2: [B, H, W, C2] concatenated
     along C), or a SplitT of that shape (pre-split operand -> DMA-fed kernel; no x2 / pre then).  Returns
     [B, OH, OW, N] (or the remapped [B, 1, out_len, N]); split_out = "only": a SplitT of the result instead,
@@ -534,6 +534,7 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = _p(out)
     if so is not None:
         d.out_split = so.data_ptr(); d.out_split_c = N
+        d.out_split_act = split_act; d.out_split_slope = split_slope   # activation on the split-image output only
     if rowbias is not None:
         if not (rowbias.dim() == 2 and rowbias.stride(1) == 1 and rowbias.shape == (B, N)):
             raise RuntimeError("conv.rowbias: need a [B, N] fp32 view with unit inner stride")

@@ -51,6 +51,17 @@ class ResnetBlock(nn.Module):
                             nin=ops.pack_conv(self.nin_shortcut.weight, self.nin_shortcut.bias)
                             if self.in_channels != self.out_channels else None)
         pk = self._pk
+        if ops.use_dma() and self.in_channels % 32 == 0 and self.out_channels % 32 == 0:
+            # round 3: like the UNet's ResBlocks — GroupNorm + swish + operand split once per element (aldm_groupnorm_split),
+            # the convs on the DMA-fed kernel over pre-split operands (csrc/igemm_dma.h; bf16x3 products in the default mode)
+            if pk["nin"] is None:
+                a1, skip = ops.gn_split(x, *pk["n1"], groups=32, eps=1e-6, act=ACT_SILU), x
+            else:
+                a1, raw = ops.gn_split(x, *pk["n1"], groups=32, eps=1e-6, act=ACT_SILU, want_raw=True)
+                skip = ops.conv(raw, pk["nin"])
+            h = ops.conv(a1, pk["c1"], pad=(1, 1))
+            a2 = ops.gn_split(h, *pk["n2"], groups=32, eps=1e-6, act=ACT_SILU)
+            return ops.conv(a2, pk["c2"], pad=(1, 1), res=skip)
         sc, sh = ops.gn_stats(x, *pk["n1"], groups=32, eps=1e-6)
         h = ops.conv(x, pk["c1"], pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU)
         sc, sh = ops.gn_stats(h, *pk["n2"], groups=32, eps=1e-6)
@@ -80,8 +91,11 @@ class AttnBlock(nn.Module):
         pk = self._pk
         B, H, W, C = x.shape
         L = H * W
-        sc, sh = ops.gn_stats(x, *pk["n"], groups=32, eps=1e-6)
-        qkv = ops.conv(x, pk["qkv"], pre=(sc, sh)).view(B, L, 3 * C)
+        if ops.use_dma() and C % 32 == 0:
+            qkv = ops.conv(ops.gn_split(x, *pk["n"], groups=32, eps=1e-6), pk["qkv"]).view(B, L, 3 * C)
+        else:
+            sc, sh = ops.gn_stats(x, *pk["n"], groups=32, eps=1e-6)
+            qkv = ops.conv(x, pk["qkv"], pre=(sc, sh)).view(B, L, 3 * C)
         scores = ops.gemm_nt(qkv[:, :, :C], qkv[:, :, C:2 * C], alpha=float(int(C) ** (-0.5)))
         probs = ops.softmax_rows(scores, 1.0)
         o = ops.gemm_packed_batched(probs, ops.pack_kn(qkv[:, :, 2 * C:]), L, C)
@@ -100,6 +114,8 @@ class _Up(nn.Module):
     def run(self, x):
         if self._pk is None:
             self._pk = ops.pack_conv(self.conv.weight, self.conv.bias)
+        if ops.use_dma() and x.shape[-1] % 32 == 0:
+            x = ops.split_rows(x)   # nearest x2 stays address generation, now over the split image
         return ops.conv(x, self._pk, pad=(1, 1), up=(2, 2))
 
 
@@ -116,7 +132,8 @@ class _Down(nn.Module):
         if self._pk is None:
             self._pk = ops.pack_conv(self.conv.weight, self.conv.bias)
         B, H, W, C = x.shape
-        return ops.conv(x, self._pk, stride=(2, 2), pad=(0, 0), out_hw=((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1))
+        xin = ops.split_rows(x) if (ops.use_dma() and C % 32 == 0) else x
+        return ops.conv(xin, self._pk, stride=(2, 2), pad=(0, 0), out_hw=((H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1))
 
 
 def _check_dd(attn_resolutions, downsample_time_stride4_levels, use_linear_attn, attn_type):

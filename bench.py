@@ -243,8 +243,12 @@ def tail_roofline(ld, B, model):
     for name, gf, a, b in (("vae_decode", VAE_DECODE_GFLOP[model], 0, 1), ("hifigan", HIFIGAN_GFLOP[model], 1, 2)):
         ms = ev[a].elapsed_time(ev[b])
         tf = gf * B / ms  # GFLOP / ms = TFLOP/s
+        from audioldm2_amd import ops as _o
+        pk = MODE_PEAK[_o.MMA_MODE] if _o.use_dma() else PEAK_BF16X6_TFLOPS
         out[name] = {"ms": round(ms, 2), "gflop_per_sample": gf, "achieved": round(tf, 1), "unit": "TFLOP/s",
-                     "peak": PEAK_BF16X6_TFLOPS, "frac": round(tf / PEAK_BF16X6_TFLOPS, 4), "bound": "mfma"}
+                     "peak": pk, "frac": round(tf / pk, 4), "bound": "mfma",
+                     "peak_note": f"{_o.MMA_MODE} products on the DMA-fed convs (most of the stage's FLOPs); the 8- / 1-channel "
+                                  "convs, the VAE mid attention and the 64- / 32-channel vocoder stages run bf16x6"}
     return out
 
 

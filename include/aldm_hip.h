@@ -150,6 +150,12 @@ typedef struct aldm_igemm_desc {
                               exact 3-way split, 6 partial products ("bf16x6"); 2 = (hi, mid) rounded to nearest, 3
                               partial products ("bf16x3": ~16 significant bits per operand, unbiased).  The register-
                               staged kernels always use the 3-part w_split.                                      */
+    /* ABI v6: an activation applied to the SPLIT-IMAGE output only (ALDM_ACT_NONE | ALDM_ACT_LRELU with out_split_slope):
+       out = v (fp32, e.g. a HiFi-GAN ResBlock's running sum x + conv(...), hifigan/models.py:96-103) while out_split =
+       split(leaky_relu(v)), the pre-activated operand of the next conv — the leaky_relu that the register-staged kernels
+       apply in their operand gather.                                                                            */
+    int32_t out_split_act;
+    float out_split_slope;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -206,6 +212,10 @@ int64_t aldm_split_image_bytes(int64_t rows, int C, int parts);
  * conv's operand, openaimodel.py:267).                                                                            */
 int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                     const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream);
+/* the same with act = ALDM_ACT_LRELU(slope) allowed as well (ABI v6): the leaky_relu in front of every HiFi-GAN conv
+ * (hifigan/models.py:98, 151) applied once while writing the operand image                                          */
+int aldm_split_rows_act(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                        const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, void* stream);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1
