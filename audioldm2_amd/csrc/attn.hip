@@ -340,7 +340,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <bool HAS_MASK, int QT, int NP>
+// PRE (round 3): K and V^T arrive PRE-SPLIT from the qkv projection's epilogue (ALDM_EPI_QKV, include/aldm_hip.h) — `k` is the
+// split image [key][heads][NP][32] bf16 of the k columns (ldk = heads), `v` the per-(sample, head, key tile) transposed image
+// [tile][NP][32 dims][32 keys] bf16 — so a key tile costs 4 + 4 16-byte loads that ARE the MFMA operands and no split
+// arithmetic (96 of the 328 VALU instructions of a tile); the products and their order are unchanged: bit-identical results.
+template <bool HAS_MASK, int QT, int NP, bool PRE = false>
 __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
@@ -379,34 +383,57 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
         }
     }
 
-    const float* kb = k + (int64_t)b * Lk * ldk + h * 32;
-    const float* vb = v + (int64_t)b * Lk * ldv + h * 32;
+    // PRE: ldk = heads (the k image's blocks per row); the images' strides follow from heads, NP and Lk
+    const int heads_ = PRE ? ldk : 0;
+    const char* kimg = reinterpret_cast<const char*>(k) + (PRE ? ((int64_t)b * Lk * heads_ + h) * (64 * NP) : 0);
+    const char* vimg = reinterpret_cast<const char*>(v) + (PRE ? ((int64_t)b * heads_ + h) * (Lk >> 5) * (int64_t)(NP * 2048) : 0);
+    const float* kb = PRE ? reinterpret_cast<const float*>(kimg) : k + (int64_t)b * Lk * ldk + h * 32;
+    const float* vb = PRE ? reinterpret_cast<const float*>(vimg) : v + (int64_t)b * Lk * ldv + h * 32;
     const float* mb = HAS_MASK ? mask + (int64_t)b * Lk : nullptr;
-    const __amdgpu_buffer_rsrc_t rk =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kb), 0, ((Lk - 1) * ldk + 32) * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, ((Lk - 1) * ldv + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(kb), 0, PRE ? ((Lk - 1) * heads_ + 1) * (64 * NP) : ((Lk - 1) * ldk + 32) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(vb), 0, PRE ? (Lk >> 5) * NP * 2048 : ((Lk - 1) * ldv + 32) * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rm =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_MASK ? mb : vb), 0, (HAS_MASK ? Lk : 1) * 4, 0x00020000);
-    const int koff = (l31 * ldk + 16 * lh) * 4;
-    const int voff = (4 * lh * ldv + l31) * 4;
+    const int koff = PRE ? l31 * heads_ * (64 * NP) + lh * 32 : (l31 * ldk + 16 * lh) * 4;
+    const int voff = PRE ? l31 * 64 + lh * 16 : (4 * lh * ldv + l31) * 4;
     const int moff = 4 * lh * 4;
 
     f32x4 kraw[4];
     float vf[16], mk[16];
+    u32x4 kpre[2][NP], vpre[2][NP];   // PRE: the landing registers hold MFMA operands already
     const int j_last = Lk - 32;   // prefetches past the end re-read the last tile (see load_tile above: the descriptor's
                                   // range check is not relied on; with Lk % 32 == 0 every offset formed here is < Lk)
     auto load_k = [&](int j0) {
-        const int sk = __builtin_amdgcn_readfirstlane(min(j0, j_last) * ldk * 4);
+        if constexpr (PRE) {
+            const int sk = __builtin_amdgcn_readfirstlane(min(j0, j_last) * heads_ * (64 * NP));
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    kpre[s][p] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * s + 64 * p, sk, 0);
+        } else {
+            const int sk = __builtin_amdgcn_readfirstlane(min(j0, j_last) * ldk * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                kraw[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * g, sk, 0));
+        }
     };
     auto load_v = [&](int j0) {
+        if constexpr (PRE) {
+            const int sv = __builtin_amdgcn_readfirstlane((min(j0, j_last) >> 5) * (NP * 2048));
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                rv, voff, __builtin_amdgcn_readfirstlane((min(j0, j_last) + (r & 3) + 8 * (r >> 2)) * ldv * 4), 0));
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    vpre[s][p] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff + 32 * s + 2048 * p, sv, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                vf[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rv, voff, __builtin_amdgcn_readfirstlane((min(j0, j_last) + (r & 3) + 8 * (r >> 2)) * ldv * 4), 0));
+        }
     };
     auto load_m = [&](int j0) {
 #pragma unroll
@@ -419,16 +446,26 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
     float m_run[QT], l_run[QT], alpha[QT], m_new[QT], tmax[QT], psum[QT];
 
     auto split_k_step = [&](int s, bf16x8 (&dst)[2][3]) {
-        float x8[8];
+        if constexpr (PRE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
-        split8_np<NP>(x8, dst[s]);
+            for (int p = 0; p < NP; ++p) dst[s][p] = __builtin_bit_cast(bf16x8, kpre[s][p]);
+        } else {
+            float x8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x8[j] = kraw[2 * s + (j >> 2)][j & 3];
+            split8_np<NP>(x8, dst[s]);
+        }
     };
     auto split_v_step = [&](int s) {
-        float x8[8];
+        if constexpr (PRE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
-        split8_np<NP>(x8, vx[s]);
+            for (int p = 0; p < NP; ++p) vx[s][p] = __builtin_bit_cast(bf16x8, vpre[s][p]);
+        } else {
+            float x8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x8[j] = vf[8 * s + j];
+            split8_np<NP>(x8, vx[s]);
+        }
     };
     auto split_p_step = [&](int t, int s) {
         float x8[8];
@@ -517,6 +554,10 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) vf[r] = 0.f;   // V_{-1} = 0
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) vpre[s][p] = u32x4{0u, 0u, 0u, 0u};
 
     // prologue: K_0 split, K_1 in flight; mask tile 0 in flight
     const int nt = Lk >> 5;
@@ -676,6 +717,48 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
 #undef ALDM_ATTN_P
 #undef ALDM_ATTN
     ALDM_LAUNCH_CHECK("aldm_attention_d32");
+    return 0;
+}
+
+extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, const void* vt_split, float* out,
+                                           void* out_split, int parts, int B, int heads, int Lq, int Lk, int ldq, int ldo,
+                                           float scale, void* stream) {
+    ALDM_CHECK(q && k_split && vt_split && (out || out_split), "aldm_attention_d32_presplit: null pointer");
+    ALDM_CHECK(parts == 2 || parts == 3, "aldm_attention_d32_presplit: parts must be 2 or 3");
+    ALDM_CHECK(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk % 32 == 0, "aldm_attention_d32_presplit: Lk must be a multiple of 32");
+    if (!out) ldo = heads * 32;
+    ALDM_CHECK(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= heads * 32 && ldo >= heads * 32,
+               "aldm_attention_d32_presplit: row pitches must be multiples of 4 and >= heads*32");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k_split) | reinterpret_cast<uintptr_t>(vt_split) |
+                 reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out_split)) & 15) == 0,
+               "aldm_attention_d32_presplit: operands must be 16-byte aligned");
+    const int gm = g_attn_mma.load();
+    const int amode = gm < 0 ? default_attn_mode() : gm;
+    ALDM_CHECK((amode == 3 && parts == 2) || (amode == 2 && parts == 3),
+               "aldm_attention_d32_presplit: %d-part images need the %s attention mode (mode in force: %d)", parts,
+               parts == 2 ? "bf16x3" : "bf16x6", amode);
+    static const int env_qt = [] {
+        const char* e = getenv("ALDM_ATTN_QT");
+        return e ? atoi(e) : 0;
+    }();
+    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 64 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
+    dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
+    hipStream_t st = (hipStream_t)stream;
+    const float* kf = reinterpret_cast<const float*>(k_split);
+    const float* vf = reinterpret_cast<const float*>(vt_split);
+    const int split_c = heads * 32;
+#define ALDM_ATTN_PRE(Q_, P_)                                                                                          \
+    hipLaunchKernelGGL((attention_d32_pipe_kernel<false, Q_, P_, true>), grid, dim3(256), 0, st, q, kf, vf, out, Lq, Lk, ldq, \
+                       heads, 0, ldo, nullptr, scale, out_split, split_c, parts)
+    if (parts == 2) {
+        if (qt2) ALDM_ATTN_PRE(2, 2);
+        else ALDM_ATTN_PRE(1, 2);
+    } else {
+        if (qt2) ALDM_ATTN_PRE(2, 3);
+        else ALDM_ATTN_PRE(1, 3);
+    }
+#undef ALDM_ATTN_PRE
+    ALDM_LAUNCH_CHECK("aldm_attention_d32_presplit");
     return 0;
 }
 

@@ -246,7 +246,9 @@ static bool dma_ws_eligible(const IgemmK& p, int BM, int BN) {
     const aldm_igemm_desc& d = p.d;
     const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (d.out_mul > 0 || d.accumulate || d.batch != 1 || d.act != ALDM_ACT_NONE || d.out_split_act != ALDM_ACT_NONE) return false;
+    if (d.out_mul > 0 || d.accumulate || d.batch != 1 || d.act != ALDM_ACT_NONE || d.out_split_act != ALDM_ACT_NONE ||
+        d.epi_mode == ALDM_EPI_QKV)
+        return false;
     if (p.M % BM != 0 || d.N % BN != 0 || (d.N & 3) != 0 || (d.ldo & 3) != 0) return false;
     if (!al16(d.out) || !al16(d.res) || !al16(d.bias) || !al16(d.rowbias) || !al16(d.out_split)) return false;
     if (d.rowbias && (p.OHW % BM != 0 || (p.rb_ld & 3) != 0)) return false;
@@ -279,7 +281,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.pix1 % 4 == 0 && d.pix2 % 4 == 0, "aldm_igemm: pixel pitch must be a multiple of 4");
     ALDM_CHECK(d.K == d.KH * d.KW * p.Cin, "aldm_igemm: K=%d != KH*KW*Cin=%d", d.K,
                d.KH * d.KW * p.Cin);
-    ALDM_CHECK(d.N > 0 && (d.ldo >= d.N || d.epi_mode == ALDM_EPI_GEGLU), "aldm_igemm: bad N=%d ldo=%d", d.N, d.ldo);
+    ALDM_CHECK(d.N > 0 && (d.ldo >= d.N || d.epi_mode == ALDM_EPI_GEGLU || d.epi_mode == ALDM_EPI_QKV),
+               "aldm_igemm: bad N=%d ldo=%d", d.N, d.ldo);
     ALDM_CHECK(d.B > 0 && d.H > 0 && d.W > 0 && d.OH > 0 && d.OW > 0, "aldm_igemm: bad extents");
     ALDM_CHECK(d.SH > 0 && d.SW > 0 && d.DH > 0 && d.DW > 0, "aldm_igemm: bad stride/dilation");
     p.shh = log2_exact(d.up_h);
@@ -303,7 +306,18 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
                    ((reinterpret_cast<uintptr_t>(d.pre_scale) | reinterpret_cast<uintptr_t>(d.pre_shift)) & 15) == 0,
                "aldm_igemm: pre_scale/pre_shift must be 16-byte aligned");
     const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
-    ALDM_CHECK(d.epi_mode == ALDM_EPI_PLAIN || geglu, "aldm_igemm: unknown epi_mode %d", d.epi_mode);
+    const bool qkv = d.epi_mode == ALDM_EPI_QKV;
+    ALDM_CHECK(d.epi_mode == ALDM_EPI_PLAIN || geglu || qkv, "aldm_igemm: unknown epi_mode %d", d.epi_mode);
+    if (qkv) {
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        ALDM_CHECK(d.a_split && d.qkv_c > 0 && d.qkv_c % 64 == 0 && d.N == 3 * d.qkv_c && d.qkv_rows > 0 && d.qkv_rows % 32 == 0 &&
+                       ((int64_t)d.B * d.OH * d.OW) % d.qkv_rows == 0 && d.out && d.k_split && d.vt_split && al16(d.out) &&
+                       al16(d.k_split) && al16(d.vt_split) && d.ldo >= d.qkv_c && (d.ldo & 3) == 0 && !d.bias && !d.rowbias &&
+                       !d.res && !d.out_split && !d.accumulate && d.out_mul == 0 && d.act == ALDM_ACT_NONE && d.alpha == 1.0f &&
+                       d.batch <= 1,
+                   "aldm_igemm: ALDM_EPI_QKV needs a pre-split operand, N = 3*qkv_c (qkv_c %% 64 == 0), qkv_rows %% 32 == 0, "
+                   "aligned out / k_split / vt_split and a plain epilogue");
+    }
     if (geglu) {
         ALDM_CHECK(d.N % 64 == 0 && d.ldo >= d.N / 2 && d.ldo % 4 == 0 && d.b_mode == ALDM_B_PACKED &&
                        d.out_mul == 0 && !d.res && !d.rowbias && !d.accumulate &&
@@ -361,7 +375,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         ALDM_CHECK(((reinterpret_cast<uintptr_t>(d.a_split) | reinterpret_cast<uintptr_t>(d.w_split)) & 15) == 0,
                    "aldm_igemm: split images must be 16-byte aligned");
         ALDM_CHECK((int64_t)d.B * d.H * d.W * p.Cin * 2 * d.split_parts < (1ll << 40), "aldm_igemm: split image too large");
-        const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu;
+        const bool can_split = d.N % 4 == 0 && nk >= 8 && !geglu && !qkv;
         const bool have_ws = d.ws != nullptr && (reinterpret_cast<uintptr_t>(d.ws) & 15) == 0;
         auto dma_cost = [&](int bm, int bn, int nst, int sp, int* sp_eff) -> double {
             const int kt = cdiv(nk, sp);
@@ -413,6 +427,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             for (int c = 0; c < 5; ++c) {
                 const int bm = cand[c][0], bn = cand[c][1];
                 if (geglu ? bn != 128 : (bn > 64 && d.N <= 64)) continue;
+                if (qkv && d.qkv_c % bn != 0) continue;
                 if (bm == 256 && Mz < 4096) continue;
                 for (int si = 0; si < 8; ++si) {
                     const int sp = sps[si];
@@ -431,6 +446,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             }
         }
         ALDM_CHECK(!geglu || BN == 128, "aldm_igemm: the GEGLU epilogue needs a 128-column tile");
+        ALDM_CHECK(!qkv || d.qkv_c % BN == 0, "aldm_igemm: the QKV epilogue needs a tile width dividing qkv_c");
+        if (qkv) splits = 1;
         p.tiles_m = cdiv(p.M, BM);
         p.tiles_n = cdiv(d.N, BN);
         p.kt_per_split = cdiv(nk, splits);

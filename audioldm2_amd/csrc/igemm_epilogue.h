@@ -111,6 +111,16 @@ __device__ __forceinline__ float silu_fast(float v) {
     return v * __frcp_rn(1.0f + __expf(-v));
 }
 
+// (hi, mid) round-to-nearest split of 8 values -> two bf16x8 (the attention kernel's split8_rn2), or the exact 3-part split
+__device__ __forceinline__ void split8_to_parts(const float (&x)[8], u32x4 (&part)[3], int parts) {
+    f32x4 a = {x[0], x[1], x[2], x[3]}, b = {x[4], x[5], x[6], x[7]};
+    u32x2 pa[3], pb[3];
+    split4_parts(a, pa, parts);
+    split4_parts(b, pb, parts);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) part[q] = u32x4{pa[q][0], pa[q][1], pb[q][0], pb[q][1]};
+}
+
 // ---- epilogue ------------------------------------------------------------------------------------------------------
 // The MFMA accumulator layout gives a lane 4-byte pieces of 16 different rows; storing those
 // directly is store-issue bound (one dword store instruction per element).  Instead each wave
@@ -146,6 +156,51 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
     const bool need_b = !split_out && (d.rowbias != nullptr || d.out_mul > 0);
     const int ld_out = split_out ? d.N : d.ldo;
     void* simg = split_out ? nullptr : d.out_split;
+    int col_shift = 0;        // ALDM_EPI_QKV: the k columns are stored from column 0 of their image
+    int simg_c = d.out_split_c;
+    if (d.epi_mode == ALDM_EPI_QKV) {
+        // the block's columns lie in ONE of the three C-wide segments (host: the tile width divides C)
+        const int seg = n0 / d.qkv_c;
+        if (seg == 2) {
+            // v: transposed per (sample, head, 32-key tile), straight from the accumulator layout.  Lane (column l31 of
+            // 32-column tile j, half lh) holds rows (e & 3) + 8 (e >> 2) + 4 lh of a 32-row slab in registers e = 0..15:
+            // registers 8s .. 8s + 7 are the 8 keys of chunk 2s + lh of its dim's 64-byte row.
+            char* vt = reinterpret_cast<char*>(d.vt_split);
+            const int heads = d.qkv_c >> 5, parts = d.split_parts;
+            const int tiles = d.qkv_rows >> 5;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mb = m0 + (wm * MT + i) * 32;
+                if (mb >= p.M) continue;
+                const int b = mb / d.qkv_rows, t = (mb - b * d.qkv_rows) >> 5;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int h = (n0 - 2 * d.qkv_c + (wn * NT + j) * 32) >> 5;
+                    char* base = vt + ((((int64_t)b * heads + h) * tiles + t) * parts) * 2048 + l31 * 64 + lh * 16;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float x8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x8[e] = acc[i][j][8 * s + e];
+                        u32x4 part[3];
+                        split8_to_parts(x8, part, parts);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            if (q < parts && epi_st) *reinterpret_cast<u32x4*>(base + q * 2048 + s * 32) = part[q];
+                    }
+                }
+            }
+            return;
+        }
+        if (seg == 1) {        // k: the split image only
+            outp = nullptr;
+            simg = d.k_split;
+            simg_c = d.qkv_c;
+            col_shift = d.qkv_c;
+        } else {               // q: fp32 only
+            simg = nullptr;
+        }
+    }
     if constexpr (NT == 2) {
         if (d.epi_mode == ALDM_EPI_GEGLU) {
             // fused GEGLU (attention.py:42-44): the wave's slab holds 32 value columns then their 32
@@ -224,7 +279,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                     orow = (int64_t)b * d.out_len + t;
                 }
             }
-            rowoff[it] = ok ? orow * ld_out + ncol : 0;
+            rowoff[it] = ok ? orow * ld_out + (ncol - col_shift) : 0;
             srow[it] = orow;
             rboff[it] = ok ? b * p.rb_ld + ncol : 0;
             okmask |= ((ok && epi_st) ? 1u : 0u) << it;
@@ -289,7 +344,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                 }
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
-                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], d.out_split_c, ncol, v[it], d.split_parts);
+                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], simg_c, ncol - col_shift, v[it], d.split_parts);
             }
         } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
 #pragma unroll

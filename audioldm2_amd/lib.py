@@ -15,7 +15,7 @@ ABI_VERSION = 6
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU, ACT_GELU_TANH = range(7)
 B_PACKED, B_NT = 0, 1
-EPI_PLAIN, EPI_GEGLU = 0, 1
+EPI_PLAIN, EPI_GEGLU, EPI_QKV = 0, 1, 2
 
 
 class IgemmDesc(C.Structure):
@@ -47,6 +47,7 @@ class IgemmDesc(C.Structure):
         ("w_split", C.c_void_p), ("hint_mma", C.c_int32), ("hint_stages", C.c_int32),
         ("a_split", C.c_void_p), ("out_split", C.c_void_p), ("out_split_c", C.c_int32), ("split_parts", C.c_int32),
         ("out_split_act", C.c_int32), ("out_split_slope", C.c_float),
+        ("k_split", C.c_void_p), ("vt_split", C.c_void_p), ("qkv_c", C.c_int32), ("qkv_rows", C.c_int32),
     ]
 
 
@@ -91,6 +92,8 @@ _SIGS = {
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_void_p]),
     "aldm_attention_mma": (C.c_int, [C.c_int]),
+    "aldm_attention_d32_presplit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_float, C.c_void_p]),

@@ -282,7 +282,13 @@ def _igemm(d: IgemmDesc, what: str, device=None):
     if TUNE_LOG is not None:
         TUNE_LOG.append(key)
     if d.a_split:
-        hint = _tuned_table("dma2" if d.split_parts == 2 else "dma").get(key)
+        if d.epi_mode == _l.EPI_QKV:   # tuned like the plain projection of the same geometry
+            d.epi_mode = _l.EPI_PLAIN
+            key_t = tune_key(d)
+            d.epi_mode = _l.EPI_QKV
+        else:
+            key_t = key
+        hint = _tuned_table("dma2" if d.split_parts == 2 else "dma").get(key_t)
         if hint is not None:
             d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = hint[:4]
     else:
@@ -445,6 +451,64 @@ def linear_geglu(x, pw: Packed, split_out: Optional[str] = None, gate_act: int =
     d.act = gate_act  # ACT_GELU_TANH: tanh-GELU gate (T5 gated-gelu FF); default erf GELU (attention.py:44)
     _igemm(d, "igemm(geglu)")
     return so if split_out == "only" else ((out, so) if split_out else out)
+
+
+def linear_qkv(x: "SplitT", pw: Packed, heads: int, rows_per_sample: int):
+    """The fused self-attention projection [q | k | v] = x W^T (pw: the three weights concatenated along N, no bias) with the
+    ALDM_EPI_QKV epilogue: returns (q fp32 [..., C], k_img, vt_img) — k as the split image of its columns, v transposed per
+    (sample, head, 32-key tile) straight from the accumulators — the operands ops.attention_presplit multiplies without
+    splitting anything in its key loop.  x: a SplitT [B, L, C_in] (DMA-fed launch)."""
+    assert isinstance(x, SplitT) and pw.KH == 1 and pw.KW == 1 and pw.bias is None
+    Cq = heads * 32
+    assert pw.N == 3 * Cq and x.shape[-1] == pw.Cin
+    M = x.rows
+    assert M % rows_per_sample == 0 and rows_per_sample % 32 == 0
+    Bn = M // rows_per_sample
+    P = x.parts
+    dev = x.device
+    q = torch.empty((*x.shape[:-1], Cq), device=dev, dtype=torch.float32)
+    k_img = torch.empty((M, heads, P, 32), device=dev, dtype=torch.int16)
+    vt_img = torch.empty((Bn, heads, rows_per_sample // 32, P, 32, 32), device=dev, dtype=torch.int16)
+    d = IgemmDesc()
+    d.a_split = x.data_ptr(); d.split_parts = P
+    d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
+    d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
+    d.OH = 1; d.OW = M
+    d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
+    d.w_split = pw.split_ptr(P)
+    d.out = q.data_ptr(); d.ldo = Cq; d.alpha = 1.0
+    d.k_split = k_img.data_ptr(); d.vt_split = vt_img.data_ptr(); d.qkv_c = Cq; d.qkv_rows = rows_per_sample
+    d.epi_mode = _l.EPI_QKV; d.batch = 1
+    _igemm(d, "igemm(qkv)")
+    return q, k_img, vt_img
+
+
+def attention_presplit(q: torch.Tensor, k_img: torch.Tensor, vt_img: torch.Tensor, heads: int, *,
+                       scale: Optional[float] = None, split_out: Optional[str] = None):
+    """Self-attention over the operands linear_qkv wrote (aldm_attention_d32_presplit): bit-identical to
+    ops.attention(q, k, v) in the same mode, without the per-key-tile operand splits."""
+    qp, Lq, ldq = _rowview(q, "attn_pre.q")
+    B = q.shape[0]
+    Lk = k_img.shape[0] // B
+    parts = k_img.shape[2]
+    assert q.shape[2] == heads * 32 and k_img.shape[1] == heads and vt_img.shape[0] == B and vt_img.shape[2] * 32 == Lk
+    if scale is None:
+        scale = 32 ** -0.5
+    out = None if split_out == "only" else torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
+    so = SplitT.empty((B, Lq, heads * 32), q.device, parts) if split_out else None
+    ev = None
+    if ATTN_PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _l.check(_l.load().aldm_attention_d32_presplit(qp, k_img.data_ptr(), vt_img.data_ptr(), _p(out),
+                                                   None if so is None else so.data_ptr(), parts, B, heads, Lq, Lk, ldq,
+                                                   heads * 32, scale, _stream()), "attention_d32_presplit")
+    if ev is not None:
+        ev[1].record()
+        ATTN_PROFILE.append((B, heads, Lq, Lk, False, 4.0 * B * heads * Lq * Lk * 32, ev[0], ev[1]))
+    if not split_out:
+        return out
+    return so if split_out == "only" else (out, so)
 
 
 def pack_convtr1d(weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int) -> List[Packed]:

@@ -21,8 +21,13 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
 from .ops import ACT_NONE, ACT_SILU
+
+# A/B switch: ALDM_ATTN_PRESPLIT=0 keeps fp32 K / V and splits them inside the attention kernel (the round-2 path)
+PRESPLIT_ATTENTION = os.environ.get("ALDM_ATTN_PRESPLIT", "1") != "0"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -217,15 +222,26 @@ class BasicTransformerBlock(nn.Module):
         # DMA mode: every GEMM operand is written pre-split by its producer (LayerNorm, attention, GEGLU epilogue)
         so = "only" if (ops.use_dma() and C % 32 == 0) else None
         n = ops.layernorm(h, *pk["ln"][0], split_out=so)
-        qkv = ops.linear(n, pk["qkv1"])
-        a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads, split_out=so)
+        # self-attention over operands the projection's epilogue pre-splits (round 3): k as a split image, v transposed per key
+        # tile — when the token count is a whole number of 32-key tiles (every UNet level of every config)
+        pre = so is not None and PRESPLIT_ATTENTION and h.shape[1] % 32 == 0
+        if pre:
+            q, kimg, vtimg = ops.linear_qkv(n, pk["qkv1"], self.heads, h.shape[1])
+            a = ops.attention_presplit(q, kimg, vtimg, self.heads, split_out=so)
+        else:
+            qkv = ops.linear(n, pk["qkv1"])
+            a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads, split_out=so)
         h = ops.linear(a, pk["out1"], res=h)
         n = ops.layernorm(h, *pk["ln"][1], split_out=so)
         if context is None:
             if pk["qkv2"] is None:
                 raise RuntimeError("attn2 was built with a context_dim but no context was provided")
-            qkv = ops.linear(n, pk["qkv2"])
-            a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads, split_out=so)
+            if pre:
+                q, kimg, vtimg = ops.linear_qkv(n, pk["qkv2"], self.heads, h.shape[1])
+                a = ops.attention_presplit(q, kimg, vtimg, self.heads, split_out=so)
+            else:
+                qkv = ops.linear(n, pk["qkv2"])
+                a = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.heads, split_out=so)
         else:
             q = ops.linear(n, pk["q2"])
             kv = self._context_kv(context, pk)

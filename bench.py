@@ -97,6 +97,8 @@ def parse():
     ap.add_argument("--no-step-probe", action="store_true")
     ap.add_argument("--cpu-ddim-steps", type=int, default=8)
     ap.add_argument("--no-strict", action="store_true", help="skip the bf16x6 (fp32-grade) re-run reported under `strict`")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations reported under `configs`")
+    ap.add_argument("--configs-steps", type=int, default=3, help="timed jobs per other configuration")
     ap.add_argument("--strict-steps", type=int, default=2, help="timed jobs of the strict re-run")
     return ap.parse_args()
 
@@ -461,6 +463,54 @@ def main():
         finally:
             aops.set_mma(prev)
             drop_graph_entries(unet._graph_cache)
+    # ---- the other BASELINE configurations at the same per-GPU batch: same job definition, `configs-steps`
+    # timed jobs each after one warm-up; the headline `value` above stays configs[1].  Single-GPU runs only (the N > 1 curve is
+    # the headline config's).
+    if world == 1 and not args.no_configs and args.model == "audioldm2-full":
+        import gc
+        from audioldm2_amd.ddim import drop_graph_entries
+        drop_graph_entries(ld.model.diffusion_model._graph_cache)
+        del ld
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["configs"] = {}
+        for name in ("audioldm_48k", "audioldm2-full-large-1150k", "audioldm2-speech-gigaspeech"):
+            try:
+                torch.manual_seed(1234)
+                m = build_model(model_name=name).to(dev)
+                m.scale_factor.fill_(0.75) if torch.is_tensor(m.scale_factor) else None
+                m.latent_t_size = 256 if "48k" not in name else 128
+                b2 = make_batch_for_text_to_audio("synthetic prompt", batchsize=B)
+                if "48k" in name:
+                    b2["log_mel_spec"] = torch.zeros((B, 1024, 256))
+                    b2["fbank"] = b2["log_mel_spec"]
+                seed_everything(42)
+                run = lambda: m.generate_batch(b2, unconditional_guidance_scale=3.5, ddim_steps=args.ddim_steps, n_gen=1, duration=10)
+                w = run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.configs_steps):
+                    w = run()
+                torch.cuda.synchronize()
+                dtc = time.perf_counter() - t0
+                secs = w.shape[-1] / float(m.sampling_rate)
+                ent = {"value": round(B * secs * args.configs_steps / dtc, 3), "unit": "audio-s/s", "steps": args.configs_steps,
+                       "warmup": 1, "ms_per_step": round(dtc / args.configs_steps * 1e3, 2), "batch": B,
+                       "audio_seconds_per_prompt": round(secs, 3), "sampling_rate": int(m.sampling_rate), "mma": aops.MMA_MODE}
+                if not args.no_step_probe:
+                    step_ms = unet_step_probe(m, b2, B)
+                    ent["unet_step_ms"] = round(step_ms, 3)
+                    ent["unet_step_tflops"] = round(2 * UNET_GFLOP_PER_FWD_SAMPLE[name] * B / step_ms, 2)
+                    ent[f"unet_step_frac_of_{aops.MMA_MODE}_peak"] = round(ent["unet_step_tflops"] / MODE_PEAK[aops.MMA_MODE], 4)
+                if not args.no_roofline:
+                    ent["roofline_tail"] = tail_roofline(m, B, name)
+                out["configs"][name] = ent
+                drop_graph_entries(m.model.diffusion_model._graph_cache)
+                del m
+                gc.collect()
+                torch.cuda.empty_cache()
+            except Exception as e:  # pragma: no cover
+                out["configs"][name] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(1, args.cpu_ddim_steps, args.ddim_steps)

@@ -51,7 +51,18 @@ enum {
  * — pack with aldm_pack_weight from a weight whose rows were permuted that way.  N (the packed
  * width, 2*C) must be a multiple of 64, ldo >= N/2, no split-K, rowbias unused; act = ALDM_ACT_GELU_TANH selects the tanh
  * GELU for the gate (the gated-GELU FF of the FLAN-T5 conditioner: wo(gelu_new(wi_0 x) * wi_1 x)), otherwise erf GELU. */
-enum { ALDM_EPI_PLAIN = 0, ALDM_EPI_GEGLU = 1 };
+/* ALDM_EPI_QKV (ABI v6, DMA-fed launches only): the fused self-attention projection [q | k | v] = x W^T (N = 3*qkv_c, no
+ * bias; attention.py:335-342) whose epilogue hands the attention kernel its operands in the form it multiplies them in:
+ *   columns [0, C)    q   -> out, fp32 [M, ldo >= C]
+ *   columns [C, 2C)   k   -> k_split: the split image [M][C/32][parts][32] of the k columns (a head = one 32-channel block)
+ *   columns [2C, 3C)  v   -> vt_split: v TRANSPOSED per (sample, head, 32-key tile), written straight from the MFMA accumulator
+ *                            layout (no LDS transposition): [b][head][tile][part][32 dims][32 keys] bf16, the keys of a tile in
+ *                            the order the attention kernel's P^T operand holds them (chunk 2s + lh = accumulator registers 8s ..
+ *                            8s + 7 of lane half lh, i.e. tile rows (r & 3) + 8 (r >> 2) + 4 lh).
+ * Requires C % 32 == 0, the block tile's width dividing C, qkv_rows (rows per sample) % 32 == 0, no split-K.  The split is the
+ * one aldm_attention_d32 applies to fp32 K / V in registers (split_parts = 2: (hi, mid) round to nearest; 3: exact), so
+ * aldm_attention_d32_presplit over these images gives bit-identical results with ~30 % fewer VALU instructions per key tile. */
+enum { ALDM_EPI_PLAIN = 0, ALDM_EPI_GEGLU = 1, ALDM_EPI_QKV = 2 };
 
 /* B-operand layouts of aldm_igemm */
 enum {
@@ -156,6 +167,11 @@ typedef struct aldm_igemm_desc {
        apply in their operand gather.                                                                            */
     int32_t out_split_act;
     float out_split_slope;
+    /* ABI v6: ALDM_EPI_QKV outputs (see the enum) */
+    void* k_split;
+    void* vt_split;
+    int32_t qkv_c;         /* C = heads * 32                                                                         */
+    int32_t qkv_rows;      /* rows (keys) per sample                                                                  */
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -269,6 +285,11 @@ int aldm_attention_d32(const float* q, const float* k, const float* v, float* ou
 int aldm_attention_d32_split(const float* q, const float* k, const float* v, float* out, void* out_split,
                              int parts, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                              const float* mask, float scale, void* stream);
+/* Self-attention over the pre-split K / V^T images an ALDM_EPI_QKV launch wrote (ABI v6): q fp32 [B, Lq, *] (row pitch ldq),
+ * k_split / vt_split as described at ALDM_EPI_QKV with `parts` parts, Lk % 32 == 0, no mask; out / out_split as
+ * aldm_attention_d32_split.  `parts` must match the attention mode in force (2 for bf16x3, 3 for bf16x6).              */
+int aldm_attention_d32_presplit(const float* q, const void* k_split, const void* vt_split, float* out, void* out_split,
+                                int parts, int B, int heads, int Lq, int Lk, int ldq, int ldo, float scale, void* stream);
 /* Matrix-core path of aldm_attention_d32, PROCESS wide: 1 = fp32 MFMA, 2 = "bf16x6" (both products as 6 bf16 partial
  * products of exact 3-part operand splits), 3 = "bf16x3" ((hi, mid) rounded to nearest, 3 partial products), -1 =
  * default: $ALDM_ATTN_MMA if set, else the engine's $ALDM_MMA, else bf16x3 ("f32" | "bf16x6" | "bf16x3"; anything else is

@@ -315,3 +315,26 @@ def test_groupnorm_split_equals_stats_then_split_rows(ops, B, P, C1, C2, act):
     if act:
         ref = F.silu(ref)
     assert rel_err(s_new.float(), ref) < (5e-6 if exact_split(ops) else 3e-5)
+
+
+@pytest.mark.parametrize("B,L,heads", [(16, 1024, 8), (4, 256, 12), (3, 64, 20), (2, 96, 2)])
+def test_qkv_epilogue_and_presplit_attention_are_bitwise_the_fp32_kv_path(ops, B, L, heads):
+    """ALDM_EPI_QKV + aldm_attention_d32_presplit (k as a split image, v transposed per key tile straight from the accumulator
+    layout) against the round-2 path (fp32 qkv, K / V split inside the attention kernel's key loop): the same products in the
+    same order -> BIT-identical attention output; and both within the GEMM tolerance of fp64."""
+    C = heads * 32
+    x = torch.randn(B, L, C, generator=g(1))
+    wq, wk, wv = (torch.randn(C, C, generator=g(2 + i)) / math.sqrt(C) for i in range(3))
+    pw = ops.pack_conv(torch.cat([wq, wk, wv], 0))
+    xs = ops.split_rows(x.cuda())
+    qkv = ops.linear(xs, pw)
+    a_old, s_old = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], heads, split_out="also")
+    q, kimg, vtimg = ops.linear_qkv(xs, pw, heads, L)
+    assert torch.equal(q, qkv[:, :, :C].contiguous())
+    assert torch.equal(kimg.view(-1), ops.split_rows(qkv[:, :, C:2 * C].contiguous()).data.view(-1))
+    a_new, s_new = ops.attention_presplit(q, kimg, vtimg, heads, split_out="also")
+    assert torch.equal(a_new, a_old) and torch.equal(s_new.data, s_old.data)
+    xd = xs.float().double().cpu()
+    sh = lambda t: t.view(B, L, heads, 32).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sh(xd @ wq.double().t()), sh(xd @ wk.double().t()), sh(xd @ wv.double().t()))
+    assert rel_err(a_new, ref.transpose(1, 2).reshape(B, L, C)) < GEMM_TOL
