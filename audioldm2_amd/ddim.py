@@ -348,11 +348,19 @@ class DDIMSampler(object):
                       corrector_kwargs=None, unconditional_guidance_scale=1.0,
                       unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None):
         """ddim.py:166-262"""
-        if ddim_use_original_steps or timesteps is not None:
-            raise NotImplementedError("DDIMSampler(HIP): only the DDIM sub-sequence path is implemented")
+        if ddim_use_original_steps:
+            # the reference's own p_sample_ddim reads `self.model.ddim_sigmas_for_original_num_steps` here (ddim.py:324-327), a
+            # buffer it registered on the SAMPLER (ddim.py:84-91): with LatentDiffusion as the model this path raises
+            # AttributeError in the reference itself, so there is no behaviour to reproduce
+            raise NotImplementedError("DDIMSampler(HIP): ddim_use_original_steps=True is not runnable in the reference either "
+                                      "(ddim.py:324-327 reads a buffer the model does not have)")
         dev = torch.device("cuda")
         b = shape[0]
         ts = self.ddim_timesteps
+        if timesteps is not None:
+            # ddim.py:198-206: sample only the first `subset_end` entries of the DDIM sequence (start from a less noisy state)
+            subset_end = int(min(timesteps / ts.shape[0], 1) * ts.shape[0]) - 1
+            ts = ts[:subset_end]
         total_steps = ts.shape[0]
         time_range = np.flip(ts)
         use_cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)

@@ -278,16 +278,16 @@ def _tuned_table(bx=False):
 
 def _igemm(d: IgemmDesc, what: str, device=None):
     lib = _l.load()
-    key = tune_key(d)
+    if d.a_split and d.epi_mode == _l.EPI_QKV:   # tuned (and logged) like the plain projection of the same geometry
+        d.epi_mode = _l.EPI_PLAIN
+        key = tune_key(d)
+        d.epi_mode = _l.EPI_QKV
+    else:
+        key = tune_key(d)
+    key_t = key
     if TUNE_LOG is not None:
         TUNE_LOG.append(key)
     if d.a_split:
-        if d.epi_mode == _l.EPI_QKV:   # tuned like the plain projection of the same geometry
-            d.epi_mode = _l.EPI_PLAIN
-            key_t = tune_key(d)
-            d.epi_mode = _l.EPI_QKV
-        else:
-            key_t = key
         hint = _tuned_table("dma2" if d.split_parts == 2 else "dma").get(key_t)
         if hint is not None:
             d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = hint[:4]

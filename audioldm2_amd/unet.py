@@ -27,7 +27,9 @@ from . import ops
 from .ops import ACT_NONE, ACT_SILU
 
 # A/B switch: ALDM_ATTN_PRESPLIT=0 keeps fp32 K / V and splits them inside the attention kernel (the round-2 path)
-PRESPLIT_ATTENTION = os.environ.get("ALDM_ATTN_PRESPLIT", "1") != "0"
+# (also off when $ALDM_ATTN_MMA pins the attention kernel to another product mode than the engine's: the images the projection
+# writes have the ENGINE's number of parts)
+PRESPLIT_ATTENTION = os.environ.get("ALDM_ATTN_PRESPLIT", "1") != "0" and "ALDM_ATTN_MMA" not in os.environ
 
 
 # ------------------------------------------------------------------------------------------------

@@ -694,3 +694,29 @@ def test_rccl_broadcast_module_on_one_gpu(tmp_path):
     mp.spawn(_rccl_alone_worker, args=(port, out), nprocs=1, join=True)
     r = torch.load(out)
     assert r["sent"] > 0 and r["same"] and r["equal"] and r["repacked"]
+
+
+def test_ddim_sampling_timesteps_subset_continues_a_full_run(ld):
+    """`DDIMSampler.ddim_sampling(timesteps=n)` (ddim.py:198-206): only the first int(min(n / S, 1) * S) - 1 entries of the DDIM
+    sequence are sampled.  With eta = 0 the update is deterministic, so restarting from the full run's intermediate state with
+    that subset must land on the full run's result."""
+    from audioldm2_amd.ddim import DDIMSampler
+    from audioldm2_amd.pipeline import seed_everything
+    B, S = 1, 8
+    batch = cases.e2e_batch(B)
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(B)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    seed_everything(3)
+    s = DDIMSampler(ld)
+    s.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+    kw = dict(unconditional_guidance_scale=3.5, unconditional_conditioning=uncond, log_every_t=1)
+    full, inter = s.ddim_sampling(cond, (B, 8, 256, 16), **kw)
+    assert len(inter["x_inter"]) == S + 1
+    n = 5
+    subset = int(min(n / S, 1) * S) - 1                      # 4 steps: sequence entries 3, 2, 1, 0
+    start = inter["x_inter"][S - subset]                     # the state after the first S - subset steps of the full run
+    part, _ = s.ddim_sampling(cond, (B, 8, 256, 16), x_T=start, timesteps=n, **kw)
+    assert rel(part, full) < 1e-5
+    with pytest.raises(NotImplementedError):
+        s.ddim_sampling(cond, (B, 8, 256, 16), ddim_use_original_steps=True, **kw)

@@ -57,6 +57,8 @@ def tune(key, lib):
     reps = 3 if flops > 2e10 else 8
     d.hint_bm = d.hint_bn = d.hint_splits = d.hint_stages = 0
     t_auto = at.time_launch(lib, d, reps)
+    if t_auto is None:
+        return None, (None, 0, 0, 0, 0), flops, (M, N, K)
     best = (t_auto, 0, 0, 0, 0)
     geglu = d.epi_mode == L.EPI_GEGLU
     for bm, bn, st in CFGS[PARTS]:
@@ -112,8 +114,22 @@ def main():
                 counts[k] = max(counts.get(k, 0), n)
         print(f"# {m}: {sum(1 for k in c if k.endswith(SUFFIX))} unique DMA-fed igemm geometries ({PARTS} parts)", flush=True)
     entries, total, saved = {}, 0.0, 0.0
+    # $DMA_TUNE_MERGE=<table.json>: start from that table's entries and tune only geometries it does not hold;
+    # $DMA_TUNE_MIN_COUNT=n: skip geometries launched fewer than n times in the 2-step job (VAE / vocoder launches run once)
+    merge = os.environ.get("DMA_TUNE_MERGE")
+    if merge and os.path.exists(merge):
+        with open(merge) as f:
+            entries = dict(json.load(f)["entries"])
+        print(f"# merging into {merge}: {len(entries)} existing entries", flush=True)
+    min_count = int(os.environ.get("DMA_TUNE_MIN_COUNT", "0"))
+    known = set(entries)
     for key, n in sorted(counts.items()):
+        if key in known or n < min_count:
+            continue
         t_auto, best, flops, mnk = tune(key, lib)
+        if t_auto is None:
+            print(f"# {key}: the default configuration does not launch on synthetic buffers, skipped", flush=True)
+            continue
         total += t_auto * n
         if best[1] and best[0] < 0.97 * t_auto:
             entries[key] = [best[1], best[2], best[3], best[4], round(best[0], 1), round(t_auto, 1)]
