@@ -317,7 +317,7 @@ def test_groupnorm_split_equals_stats_then_split_rows(ops, B, P, C1, C2, act):
     assert rel_err(s_new.float(), ref) < (5e-6 if exact_split(ops) else 3e-5)
 
 
-@pytest.mark.parametrize("B,L,heads", [(16, 1024, 8), (4, 256, 12), (3, 64, 20), (2, 96, 2)])
+@pytest.mark.parametrize("B,L,heads", [(16, 1024, 8), (4, 256, 12), (3, 64, 20), (2, 96, 2), (2, 32, 2)])
 def test_qkv_epilogue_and_presplit_attention_are_bitwise_the_fp32_kv_path(ops, B, L, heads):
     """ALDM_EPI_QKV + aldm_attention_d32_presplit (k as a split image, v transposed per key tile straight from the accumulator
     layout) against the round-2 path (fp32 qkv, K / V split inside the attention kernel's key loop): the same products in the

@@ -1,5 +1,9 @@
-"""GroupNorm statistics launch times on the UNet's shapes (16 samples = batch 8 with CFG), 20 launches per HIP-graph replay.
-ALDM_GN_FUSED_MAX=<elements> moves the boundary between the one-launch (group-sliced) and the chunked two-launch form."""
+"""GroupNorm launch times on the UNet's shapes (16 samples = batch 8 with CFG), 20 launches per HIP-graph replay.
+Default: the statistics alone (ops.gn_stats); --split: statistics + apply + SiLU + operand split (ops.gn_split, what the UNet calls).
+Environment switches (read once per process by norm.hip): ALDM_GN_FUSED_MAX=<elements> moves the boundary between the one-launch
+(group-sliced) and the chunked two-launch form; ALDM_GN_SPLIT_FUSED=0 keeps the split in its own launch.  (ALDM_GN_THREADS /
+ALDM_GN_MIN_BLOCKS of profiles/r03_gn_split_bench.txt belong to an experiment that was not kept: its diff is in profiles/.)"""
+import os
 import sys
 
 import torch
@@ -17,7 +21,10 @@ for H, W, C1, C2, n in ((32, 2, 640, 0, 6), (32, 2, 640, 640, 3), (32, 2, 1280, 
     x = torch.randn(B, H, W, C1, generator=g).cuda()
     x2 = torch.randn(B, H, W, C2, generator=g).cuda() if C2 else None
     ga, be = torch.ones(C1 + C2).cuda(), torch.zeros(C1 + C2).cuda()
-    fn = lambda: ops.gn_stats(x, ga, be, groups=32, eps=1e-5, x2=x2)
+    if "--split" in sys.argv:
+        fn = lambda: ops.gn_split(x, ga, be, groups=32, eps=1e-5, x2=x2, act=ops.ACT_SILU)
+    else:
+        fn = lambda: ops.gn_stats(x, ga, be, groups=32, eps=1e-5, x2=x2)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -39,5 +46,5 @@ for H, W, C1, C2, n in ((32, 2, 640, 0, 6), (32, 2, 640, 640, 3), (32, 2, 1280, 
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e3 / 100
     tot += t * n
-    print(f"gn_stats P={H * W:5d} C={C1}+{C2}: {t:6.1f} us  (~{n} per UNet pass)", flush=True)
-print(f"weighted total {tot:.0f} us per UNet pass")
+    print(f"{'gn_split' if '--split' in sys.argv else 'gn_stats'} P={H * W:5d} C={C1}+{C2}: {t:6.1f} us  (~{n} per UNet pass)", flush=True)
+print(f"weighted total {tot:.0f} us per UNet pass   [" + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("ALDM_GN")) + "]")
