@@ -13,7 +13,8 @@ metric = audio-seconds / second (whole job, all GPUs).  Weak scaling: per-GPU ba
 Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant igemm kernel and the attention
 kernel, measured live with events on the launch stream; the cost of an empty event pair, measured in the same run,
 is subtracted from every bracketed launch so the durations compare with rocprofv3's kernel-only ones), `strict`
-(the same job re-run in the same invocation with fp32-grade bf16x6 products: value, UNet step, roofline) and
+(the same job re-run in the same invocation with fp32-grade bf16x6 products: value, UNet step, roofline), `configs`
+(N = 1 only: the other three BASELINE configurations at batch 8, `--configs-steps` timed jobs each: value, UNet step, tail) and
 `cpu_baseline` (the CPU oracle = the reference's arithmetic on the host cores, bounded sample).  `dtype` and every
 `*_frac_of_*_peak` name the arithmetic that actually ran.
 """
