@@ -836,10 +836,55 @@ def super_resolution_and_inpainting(latent_diffusion, text, transcription="", or
             freq_mask_ratio_start_and_end=freq_mask_ratio_start_and_end)
 
 
+# The reference's `target` strings of the sampling path (utils.py:127-561) -> their MI355X counterparts.
+REFERENCE_TARGETS = {
+    "audioldm2.latent_diffusion.models.ddpm.LatentDiffusion": "audioldm2_amd.pipeline.LatentDiffusion",
+    "audioldm2.latent_diffusion.modules.diffusionmodules.openaimodel.UNetModel": "audioldm2_amd.unet.UNetModel",
+    "audioldm2.latent_encoder.autoencoder.AutoencoderKL": "audioldm2_amd.vae.AutoencoderKL",
+    "audioldm2.latent_diffusion.modules.encoders.modules.SequenceGenAudioMAECond": "audioldm2_amd.seqgen.SequenceGenAudioMAECond",
+    "audioldm2.latent_diffusion.modules.encoders.modules.AudioMAEConditionCTPoolRand":
+        "audioldm2_amd.seqgen.AudioMAEConditionCTPoolRand",
+    "audioldm2.latent_diffusion.modules.encoders.modules.FlanT5HiddenState": "audioldm2_amd.t5.FlanT5HiddenState",
+    "audioldm2.latent_diffusion.modules.encoders.modules.PhonemeEncoder": "audioldm2_amd.phoneme.PhonemeEncoder",
+    "audioldm2.latent_diffusion.modules.encoders.modules.CLAPAudioEmbeddingClassifierFreev2":
+        "audioldm2_amd.clap.CLAPAudioEmbeddingClassifierFreev2",
+}
+
+
+def retarget_config(config):
+    """A reference model config — the dict `audioldm2.utils.default_audioldm_config(name)` returns, or the path of a YAML file
+    as `build_model(config=...)` takes it (pipeline.py:155-157) — with every `target` of the sampling path replaced by its
+    MI355X counterpart (REFERENCE_TARGETS).  Params are passed through untouched (the constructors take the reference's
+    kwargs); training-only sub-configs whose target has no counterpart (`lossconfig`: LPIPSWithDiscriminator) are dropped.
+    A config that already names `audioldm2_amd.*` targets comes back unchanged."""
+    if isinstance(config, str):
+        import yaml
+        with open(config, "r") as f:
+            config = yaml.load(f, Loader=yaml.FullLoader)
+
+    def walk(node):
+        if isinstance(node, dict):
+            out = {}
+            for k, v in node.items():
+                if isinstance(v, dict) and isinstance(v.get("target"), str) and v["target"].startswith("audioldm2.") \
+                        and v["target"] not in REFERENCE_TARGETS:
+                    continue   # no sampling-path counterpart (losses, discriminators)
+                out[k] = walk(v)
+            if isinstance(out.get("target"), str):
+                out["target"] = REFERENCE_TARGETS.get(out["target"], out["target"])
+            return out
+        if isinstance(node, (list, tuple)):
+            return type(node)(walk(v) for v in node)
+        return node
+    return walk(config)
+
+
 def build_model(ckpt_path=None, config=None, device=None, model_name="audioldm2-full"):
-    """pipeline.py:142-179.  Builds the HIP LatentDiffusion; loads `ckpt_path` when given (there is
-    no network here, so nothing is downloaded — without a checkpoint weights are random-init)."""
-    cfg = default_audioldm_config(model_name) if config is None else config
+    """pipeline.py:142-179.  Builds the HIP LatentDiffusion; `config`: None (the built-in config of `model_name`), a config
+    dict, or — like the reference — the path of a YAML file; reference `target` strings are mapped to ours
+    (retarget_config).  Loads `ckpt_path` when given (there is no network here, so nothing is downloaded — without a
+    checkpoint weights are random-init)."""
+    cfg = default_audioldm_config(model_name) if config is None else retarget_config(config)
     ld = LatentDiffusion(**cfg["model"]["params"])
     if ckpt_path is not None:
         ckpt = torch.load(ckpt_path, map_location="cpu")

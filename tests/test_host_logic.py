@@ -446,3 +446,64 @@ def test_t5_and_phoneme_host_logic_match_reference_fixtures(monkeypatch):
     emb, pm = pe(cases.phoneme_input())
     wantp = torch.from_numpy(gp["emb"])
     assert float((emb - wantp).abs().max() / wantp.abs().max()) < 1e-5 and np.array_equal(pm.numpy(), gp["mask"])
+
+
+def test_retarget_config_maps_the_reference_configs_onto_the_hip_targets(tmp_path):
+    """pipeline.retarget_config / build_model(config=<yaml path>) (pipeline.py:155-157): the reference's own config dicts
+    (utils.py:116-561), as dicts and through a YAML file, come out with our targets and untouched params — and equal the
+    configs `default_audioldm_config(..., conditioners="hip")` builds."""
+    import yaml
+    from oracle import refimport
+    if not refimport.available():
+        pytest.skip("reference not present")
+    refimport.install()
+    from audioldm2.utils import default_audioldm_config as ref_config
+    from audioldm2_amd import pipeline as P
+
+    def targets(node, acc):
+        if isinstance(node, dict):
+            if "target" in node:
+                acc.append(node["target"])
+            for v in node.values():
+                targets(v, acc)
+        return acc
+
+    for name in ("audioldm2-full", "audioldm2-full-large-1150k", "audioldm2-speech-gigaspeech", "audioldm_48k"):
+        ref = ref_config(name)
+        ours = P.retarget_config(ref)
+        assert all(t.startswith("audioldm2_amd.") for t in targets(ours, [])), targets(ours, [])
+        assert ref["model"]["target"].startswith("audioldm2.")                       # the input is not modified
+        mp = ours["model"]["params"]
+        hip = P.default_audioldm_config(name, conditioners="hip")["model"]["params"]
+        assert mp["unet_config"] == hip["unet_config"]
+        assert mp["first_stage_config"]["params"]["ddconfig"] == hip["first_stage_config"]["params"]["ddconfig"]
+        assert "lossconfig" not in mp["first_stage_config"]["params"]                 # training only: no counterpart
+        want = P.hip_cond_stage_config(name)
+        if "-speech-" in name:   # our config names the device explicitly; the reference's speech config leaves the default
+            want["crossattn_audiomae_generated"]["params"].pop("device")
+        assert mp["cond_stage_config"] == want
+        assert list(mp["cond_stage_config"].keys()) == list(ref["model"]["params"]["cond_stage_config"].keys())
+        path = tmp_path / f"{name}.yaml"
+        with open(path, "w") as f:
+            yaml.safe_dump(ref, f)
+        assert P.retarget_config(str(path)) == ours
+        assert P.retarget_config(ours) == ours                                        # idempotent
+
+
+def test_build_model_from_a_reference_yaml_builds_the_hip_module_tree(tmp_path):
+    """build_model(config=<path of the reference's YAML>) (pipeline.py:155-157) constructs OUR LatentDiffusion, UNet, VAE and
+    conditioner from the reference's config of audioldm_48k (the smallest conditioner stack: CLAP text)."""
+    import yaml
+    from oracle import refimport
+    if not refimport.available():
+        pytest.skip("reference not present")
+    refimport.install()
+    from audioldm2.utils import default_audioldm_config as ref_config
+    from audioldm2_amd import pipeline as P
+    path = tmp_path / "audioldm_48k.yaml"
+    with open(path, "w") as f:
+        yaml.safe_dump(ref_config("audioldm_48k"), f)
+    ld = P.build_model(config=str(path), model_name="audioldm_48k")
+    mods = [type(ld), type(ld.model.diffusion_model), type(ld.first_stage_model)] + [type(m) for m in ld.cond_stage_models]
+    assert all(t.__module__.startswith("audioldm2_amd.") for t in mods), mods
+    assert ld.sampling_rate == 48000 and ld.first_stage_model.decoder is not None
