@@ -836,6 +836,31 @@ def super_resolution_and_inpainting(latent_diffusion, text, transcription="", or
             freq_mask_ratio_start_and_end=freq_mask_ratio_start_and_end)
 
 
+def save_wave(waveform, savepath, name="outwav", samplerate=16000):
+    """utils.py:53-77: write waveform [B, 1, samples] as B .wav files under `savepath`, named like the reference names them
+    (`<name>_<i>.wav` for a batch, `<name>.wav` for one clip; a name that already carries `.wav` keeps only its stem; a
+    too-long single name is replaced by a hash).  The reference writes through `soundfile` (16-bit PCM, libsndfile's
+    default for .wav); soundfile is not a dependency here, so the same 16-bit PCM goes through scipy.  Returns the paths."""
+    from scipy.io import wavfile
+    if type(name) is not list:
+        name = [name] * waveform.shape[0]
+    paths = []
+    for i in range(waveform.shape[0]):
+        base = os.path.basename(name[i])
+        if waveform.shape[0] > 1:
+            fname = "%s_%s.wav" % (base if ".wav" not in name[i] else base.split(".")[0], i)
+        else:
+            fname = "%s.wav" % base if ".wav" not in name[i] else base.split(".")[0]
+            if len(fname) > 255:   # avoid a file name too long to be saved
+                fname = f"{hex(hash(fname))}.wav"
+        path = os.path.join(savepath, fname)
+        print("Save audio to %s" % path)
+        x = np.asarray(waveform[i, 0], dtype=np.float64)
+        wavfile.write(path, int(samplerate), np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16))
+        paths.append(path)
+    return paths
+
+
 # The reference's `target` strings of the sampling path (utils.py:127-561) -> their MI355X counterparts.
 REFERENCE_TARGETS = {
     "audioldm2.latent_diffusion.models.ddpm.LatentDiffusion": "audioldm2_amd.pipeline.LatentDiffusion",

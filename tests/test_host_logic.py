@@ -507,3 +507,33 @@ def test_build_model_from_a_reference_yaml_builds_the_hip_module_tree(tmp_path):
     mods = [type(ld), type(ld.model.diffusion_model), type(ld.first_stage_model)] + [type(m) for m in ld.cond_stage_models]
     assert all(t.__module__.startswith("audioldm2_amd.") for t in mods), mods
     assert ld.sampling_rate == 48000 and ld.first_stage_model.decoder is not None
+
+
+def test_save_wave_names_files_like_the_reference(tmp_path):
+    """pipeline.save_wave vs the reference's utils.save_wave (utils.py:53-77) run with its `soundfile` stubbed: the same paths
+    for batches, single clips, list names and names that carry `.wav`; the files are readable 16-bit PCM of the input."""
+    from scipy.io import wavfile
+    from oracle import refimport
+    from audioldm2_amd.pipeline import save_wave
+    rng = np.random.default_rng(0)
+    cases_ = [(rng.uniform(-0.5, 0.5, (3, 1, 1600)).astype(np.float32), "outwav"),
+              (rng.uniform(-0.5, 0.5, (1, 1, 800)).astype(np.float32), "a dog barking"),
+              (rng.uniform(-0.5, 0.5, (2, 1, 800)).astype(np.float32), ["x/first.wav", "second"]),
+              (rng.uniform(-0.5, 0.5, (1, 1, 800)).astype(np.float32), "y" * 300)]
+    ref_paths = None
+    if refimport.available():
+        refimport.install()
+        import audioldm2.utils as ru
+        written = []
+        ru.sf.write = lambda path, data, samplerate: written.append(path)
+        for w, n in cases_:
+            ru.save_wave(w, str(tmp_path), name=n, samplerate=16000)
+        ref_paths = written
+    ours = []
+    for w, n in cases_:
+        ours += save_wave(w, str(tmp_path), name=n, samplerate=16000)
+    if ref_paths is not None:
+        assert ours == ref_paths
+    sr, data = wavfile.read(ours[0])
+    assert sr == 16000 and data.dtype == np.int16 and data.shape == (1600,)
+    assert np.abs(data / 32768.0 - cases_[0][0][0, 0]).max() <= 0.5 / 32768 + 1e-9
