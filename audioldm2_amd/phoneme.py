@@ -148,3 +148,31 @@ class PhonemeEncoder(nn.Module):
             x = ops.layernorm(ops.rowscale_add(h, mask, res=x), *L["ln2"])                 # :413, :83-85
         out = ops.rowscale_add(x, mask, res=pk["pos"].unsqueeze(0).expand(B, T, C).contiguous())   # :86, modules.py:103
         return [out, mask]
+
+
+# ---- phoneme string -> ids (latent_diffusion/util.py:14-49) --------------------------------------------------------------
+# The VITS symbol inventory the speech checkpoints were trained on: pad, punctuation, Latin letters, IPA letters, specials —
+# 183 entries = PhonemeEncoder(vocabs_size=183).  The apostrophe occurs twice in the IPA block; like the reference's dict
+# comprehension the LAST occurrence wins.
+VITS_PAD_LENGTH = 310
+VITS_SYMBOLS = (["_"] + list(';:,.!?¡¿—…"«»“” ') + list("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz") +
+                list("ɑɐɒæɓʙβɔɕçɗɖðʤəɘɚɛɜɝɞɟʄɡɠɢʛɦɧħɥʜɨɪʝɭɬɫɮʟɱɯɰŋɳɲɴøɵɸθœɶʘɹɺɾɻʀʁɽʂʃʈʧʉʊʋⱱʌɣɤʍχʎʏʑʐʒʔʡʕʢǀǁǂǃˈˌːˑʼʴʰʱʲʷˠˤ˞↓↑→↗↘'̩'ᵻ") +
+                list("♪☎☒☝⚠"))
+_VITS_SYMBOL_TO_ID = {sym: i for i, sym in enumerate(VITS_SYMBOLS)}
+
+
+def phoneme_ids(phonemes, batchsize: int = 1, pad_length: int = VITS_PAD_LENGTH) -> torch.Tensor:
+    """`phoneme_idx` [batchsize, pad_length] of an ALREADY phonemised transcription (an IPA string, what the reference's
+    `text2phoneme` = phonemizer / espeak front end returns; that front end is out of scope here): the string plus the end
+    mark, one id per character, unknown characters -> the pad symbol "_" (with the reference's message), cut / zero-padded
+    to pad_length, the same row for every sample — latent_diffusion/util.py:28-49."""
+    seq = []
+    text = phonemes + "⚠"
+    for sym in text:
+        if sym not in _VITS_SYMBOL_TO_ID:
+            print("%s is not in the vocabulary. %s" % (sym, text))
+            sym = "_"
+        seq.append(_VITS_SYMBOL_TO_ID[sym])
+    seq = seq[:pad_length]
+    seq = seq + [0] * (pad_length - len(seq))
+    return torch.LongTensor(seq).unsqueeze(0).expand(batchsize, -1)

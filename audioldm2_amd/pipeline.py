@@ -720,15 +720,33 @@ class LatentDiffusion(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+# The reference turns a transcription into an IPA string with phonemizer / espeak (`text2phoneme`, pipeline.py:33-34: a text
+# front end like the tokenizers, not installed here).  Set this to a callable(text) -> IPA string to use the speech models
+# from raw text; a transcription without it raises instead of silently conditioning on silence.
+TEXT2PHONEME = None
+
+
 def make_batch_for_text_to_audio(text, transcription="", waveform=None, fbank=None, batchsize=1):
-    """pipeline.py:82-121 (phoneme ids come from the reference's text front-end and are only consumed
-    by the out-of-scope TTS conditioner; a zero tensor of the reference's shape keeps the dict layout)."""
+    """pipeline.py:82-121.  `transcription` (speech models): phonemised by TEXT2PHONEME, then mapped to `phoneme_idx` like
+    latent_diffusion/util.py:28-49 (phoneme.phoneme_ids); without a transcription the row is the end mark alone, as in the
+    reference.  `waveform` (only read by the AudioMAE conditioner, whose output no sampling path consumes) is not taken."""
+    from .phoneme import phoneme_ids
+    if transcription:
+        if TEXT2PHONEME is None:
+            raise RuntimeError("make_batch_for_text_to_audio: a transcription needs the phonemizer front end the reference "
+                               "uses (text2phoneme, pipeline.py:33) — set audioldm2_amd.pipeline.TEXT2PHONEME to a "
+                               "callable(text) -> IPA string, or put `phoneme_idx` into the batch yourself")
+        transcription = TEXT2PHONEME(transcription)
+    if waveform is not None:
+        raise NotImplementedError("make_batch_for_text_to_audio(waveform=...): the kaldi fbank front end "
+                                  "(extract_kaldi_fbank_feature, torchaudio) feeds only the AudioMAE conditioner, whose "
+                                  "output no sampling path reads; not built")
     text = [text] * batchsize
     fbank = torch.zeros((batchsize, 1024, 64)) if fbank is None else torch.FloatTensor(fbank).expand(batchsize, 1024, 64)
     batch = {"text": text, "fname": [t.replace(" ", "_").replace("'", "_").replace('"', "_") for t in text],
              "waveform": torch.zeros((batchsize, 160000)), "stft": torch.zeros((batchsize, 1024, 512)),
              "log_mel_spec": fbank, "ta_kaldi_fbank": torch.zeros((batchsize, 1024, 128)),
-             "phoneme_idx": torch.zeros((batchsize, 310), dtype=torch.long)}
+             "phoneme_idx": phoneme_ids(transcription or "", batchsize)}
     batch["fbank"] = fbank
     return batch
 

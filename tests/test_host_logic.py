@@ -537,3 +537,31 @@ def test_save_wave_names_files_like_the_reference(tmp_path):
     sr, data = wavfile.read(ours[0])
     assert sr == 16000 and data.dtype == np.int16 and data.shape == (1600,)
     assert np.abs(data / 32768.0 - cases_[0][0][0, 0]).max() <= 0.5 / 32768 + 1e-9
+
+
+def test_phoneme_ids_and_batch_layout_match_the_reference():
+    """phoneme.phoneme_ids vs latent_diffusion/util.py:28-49 (known, unknown, over-long strings); make_batch_for_text_to_audio
+    vs pipeline.py:82-121 for a prompt without transcription (every tensor the reference puts into the batch), and the
+    transcription path: refused without a phonemizer hook, mapped through it when set."""
+    from oracle import refimport
+    from audioldm2_amd import pipeline as P
+    from audioldm2_amd.phoneme import VITS_SYMBOLS, phoneme_ids
+    assert len(VITS_SYMBOLS) == 183
+    if refimport.available():
+        refimport.install()
+        from audioldm2.latent_diffusion.util import get_vits_phoneme_ids_no_padding as ref_ids
+        from audioldm2.pipeline import make_batch_for_text_to_audio as ref_batch
+        for s in ("", "həlˈoʊ wˈɜːld, ðɪs ɪz ɐ tˈɛst!", "it's 'quoted' § unknown", "a" * 400):
+            assert torch.equal(phoneme_ids(s, 3), ref_ids([s] * 3)["phoneme_idx"])
+        rb, ob = ref_batch("a dog barking", batchsize=2), P.make_batch_for_text_to_audio("a dog barking", batchsize=2)
+        for k, v in rb.items():
+            assert k in ob, k
+            assert (torch.equal(v, ob[k]) if torch.is_tensor(v) else v == ob[k]), k
+    with pytest.raises(RuntimeError, match="TEXT2PHONEME"):
+        P.make_batch_for_text_to_audio("x", transcription="hello world")
+    P.TEXT2PHONEME = lambda t: "həlˈoʊ"
+    try:
+        b = P.make_batch_for_text_to_audio("x", transcription="hello", batchsize=2)
+        assert torch.equal(b["phoneme_idx"], phoneme_ids("həlˈoʊ", 2))
+    finally:
+        P.TEXT2PHONEME = None
