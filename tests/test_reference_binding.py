@@ -237,3 +237,48 @@ def test_prompts_to_waveform_through_the_hip_conditioner_stack():
     assert e_clap < 2e-4 and e_t5 < 2e-4 and e_tok < 5e-4
     assert e_lat < 2e-4
     assert max(eh, ed) < 1e-3 and max(eh, ed) < 1e-3 * float(g["wave_between_rms"])
+
+
+@pytest.mark.skipif(not refimport.available(), reason="needs the reference checkout (build container only)")
+def test_schedule_and_conditioning_helpers_equal_the_reference_methods():
+    """q_sample / predict_start_from_noise / q_posterior / get_learned_conditioning / filter_useful_cond_dict of OUR
+    LatentDiffusion against the same methods of the REAL reference class (ddpm.py:357-373, 430-436, 804-828, 958-971) built
+    with the same config: bit-equal (the tables are the same fp32 numbers, the arithmetic the same torch expressions)."""
+    refimport.install()
+    import audioldm2.latent_diffusion.models.ddpm as rddpm
+    import audioldm2.utils as ru
+    from audioldm2_amd import pipeline as P
+    rp = ru.default_audioldm_config("audioldm2-full")["model"]["params"]
+    rp["unet_config"]["target"] = "audioldm2_amd.unet.UNetModel"
+    rp["first_stage_config"]["target"] = "audioldm2_amd.vae.AutoencoderKL"
+    rp["cond_stage_config"] = cases.e2e_cond_config("cpu")
+    rp["device"] = "cpu"
+    ref = rddpm.LatentDiffusion(**rp).eval()
+    op = P.default_audioldm_config("audioldm2-full")["model"]["params"]
+    op["cond_stage_config"] = cases.e2e_cond_config("cpu")
+    op["device"], op["build_clap"] = "cpu", False
+    ours = P.LatentDiffusion(**op).eval()
+    g = torch.Generator().manual_seed(0)
+    x0, xt, eps = (torch.randn(3, 8, 16, 16, generator=g) for _ in range(3))
+    t = torch.tensor([0, 417, 999])
+    assert torch.equal(ours.q_sample(x0, t, eps), ref.q_sample(x0, t, eps))
+    assert torch.equal(ours.predict_start_from_noise(xt, t, eps), ref.predict_start_from_noise(xt, t, eps))
+    for a, b in zip(ours.q_posterior(x0, xt, t), ref.q_posterior(x0, xt, t)):
+        assert torch.equal(a.expand_as(b), b)
+    torch.manual_seed(7)
+    a = ours.q_sample(x0, t)
+    torch.manual_seed(7)
+    assert torch.equal(a, ref.q_sample(x0, t))                        # the same randn_like draw when no noise is given
+    batch = cases.e2e_batch(2)
+    for key, meta in ref.cond_stage_model_metadata.items():
+        xc = batch if meta["cond_stage_key"] == "all" else batch[meta["cond_stage_key"]]
+        u_ref = ref.get_learned_conditioning(xc, key, unconditional_cfg=True)
+        u_our = ours.get_learned_conditioning(xc, key, unconditional_cfg=True)
+        flat = lambda v: list(v) if isinstance(v, (list, tuple)) else [v]
+        for p, q in zip(flat(u_our), flat(u_ref)):
+            assert torch.equal(p, q), key
+    d = {k: torch.zeros(1) for k in ref.cond_stage_model_metadata}
+    d["noise"] = torch.ones(1)
+    assert list(ours.filter_useful_cond_dict(d).keys()) == list(ref.filter_useful_cond_dict(d).keys())
+    with pytest.raises(AssertionError):
+        ours.filter_useful_cond_dict({"noise": d["noise"]})
