@@ -614,7 +614,32 @@ class LatentDiffusion(nn.Module):
         if len(mel.size()) == 4:
             mel = mel.squeeze(1)
         waveform = self.first_stage_model.vocoder.forward_cl(mel.float().contiguous())
-        return waveform.cpu().detach().numpy()
+        waveform = waveform.cpu().detach().numpy()
+        if save:
+            self.save_waveform(waveform, savepath, name)
+        return waveform
+
+    global_step = 0   # the Lightning trainer's step counter in the reference; part of save_waveform's file names
+
+    def save_waveform(self, waveform, savepath, name="outwav"):
+        """ddpm.py:1393-1415: every clip peak-normalised to 0.8 and written as `<global_step>_<i>_<name>.wav` (one name for the
+        batch) or `<name[i]>.wav` (a list of names; a name that carries `.wav` keeps only its stem).  16-bit PCM through scipy
+        (the reference: soundfile's default for .wav).  Returns the paths."""
+        from scipy.io import wavfile
+        paths = []
+        for i in range(waveform.shape[0]):
+            if type(name) is str:
+                path = os.path.join(savepath, "%s_%s_%s.wav" % (self.global_step, i, name))
+            elif type(name) is list:
+                base = os.path.basename(name[i])
+                path = os.path.join(savepath, "%s.wav" % (base if ".wav" not in name[i] else base.split(".")[0]))
+            else:
+                raise NotImplementedError
+            x = np.asarray(waveform[i, 0], dtype=np.float64)
+            x = (x / np.max(np.abs(x))) * 0.8   # normalize the energy of the generation output
+            wavfile.write(path, int(self.sampling_rate), np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16))
+            paths.append(path)
+        return paths
 
     def _check_candidates(self, n_gen, text=None):
         """Fail BEFORE sampling: n_candidate_gen_per_text > 1 ends in CLAP re-ranking (ddpm.py:1554-1568), which

@@ -565,3 +565,21 @@ def test_phoneme_ids_and_batch_layout_match_the_reference():
         assert torch.equal(b["phoneme_idx"], phoneme_ids("həlˈoʊ", 2))
     finally:
         P.TEXT2PHONEME = None
+
+
+def test_save_waveform_names_and_normalises_like_the_reference(tmp_path):
+    """LatentDiffusion.save_waveform (ddpm.py:1393-1415): `<global_step>_<i>_<name>.wav` for one name, `<name[i]>.wav` (stem of a
+    name that carries .wav) for a list; every clip peak-normalised to 0.8."""
+    from types import SimpleNamespace
+    from scipy.io import wavfile
+    from audioldm2_amd.pipeline import LatentDiffusion
+    me = SimpleNamespace(global_step=0, sampling_rate=16000)
+    w = np.random.default_rng(1).uniform(-0.3, 0.3, (2, 1, 1600)).astype(np.float32)
+    p = LatentDiffusion.save_waveform(me, w, str(tmp_path), "outwav")
+    assert [os.path.basename(x) for x in p] == ["0_0_outwav.wav", "0_1_outwav.wav"]
+    q = LatentDiffusion.save_waveform(me, w, str(tmp_path), ["a/b/first.wav", "second"])
+    assert [os.path.basename(x) for x in q] == ["first.wav", "second.wav"]
+    sr, d = wavfile.read(p[1])
+    assert sr == 16000 and abs(np.abs(d).max() / 32768.0 - 0.8) < 1e-4
+    with pytest.raises(NotImplementedError):
+        LatentDiffusion.save_waveform(me, w, str(tmp_path), 3)
