@@ -511,3 +511,41 @@ class DDIMSampler(object):
         noise = (noise * temperature).to(x.device)
         x_prev, pred_x0 = ops.ddim_step(x.float().contiguous(), eps, noise.contiguous(), coef.to(x.device))
         return x_prev, pred_x0
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """ddim.py:434-449: x0 noised to DDIM index t (fast, no exact reconstruction): sqrt(a_t) x0 + sqrt(1 - a_t) noise,
+        the noise from the host generator when not given (a CPU reference run's `randn_like`)."""
+        if use_original_steps:
+            sa, so = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        else:
+            sa, so = torch.sqrt(self.ddim_alphas), torch.from_numpy(np.asarray(self.ddim_sqrt_one_minus_alphas))
+        if noise is None:
+            noise = torch.randn(x0.shape)
+        tt = t.detach().cpu().long()
+        shape = (x0.shape[0],) + (1,) * (x0.dim() - 1)
+        a = sa.float()[tt].reshape(shape).to(x0.device)
+        b = so.float()[tt].reshape(shape).to(x0.device)
+        return a * x0 + b * noise.to(x0.device)
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None):
+        """ddim.py:452-491: run the last `t_start` DDIM steps from x_latent (one p_sample_ddim per step: the eager path over
+        the same kernels as ddim_sampling; the step noise comes from the host generator in the reference's order)."""
+        if use_original_steps:
+            raise NotImplementedError("DDIMSampler(HIP): use_original_steps=True is not runnable in the reference either "
+                                      "(ddim.py:324-327 reads a buffer the model does not have)")
+        timesteps = self.ddim_timesteps[:t_start]
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        x_dec = x_latent
+        for i, step in enumerate(time_range):
+            index = total_steps - i - 1
+            ts = torch.full((x_latent.shape[0],), int(step), device=x_latent.device, dtype=torch.long)
+            x_dec, _ = self.p_sample_ddim(x_dec, cond, ts, index=index, use_original_steps=use_original_steps,
+                                          unconditional_guidance_scale=unconditional_guidance_scale,
+                                          unconditional_conditioning=unconditional_conditioning)
+            if callback:
+                callback(i)
+        return x_dec

@@ -720,3 +720,14 @@ def test_ddim_sampling_timesteps_subset_continues_a_full_run(ld):
     assert rel(part, full) < 1e-5
     with pytest.raises(NotImplementedError):
         s.ddim_sampling(cond, (B, 8, 256, 16), ddim_use_original_steps=True, **kw)
+    # DDIMSampler.decode (ddim.py:452-491): the last `t_start` steps from a given state, one eager p_sample_ddim per step —
+    # the same continuation through the other entry point
+    dec = s.decode(start.clone(), cond, subset, unconditional_guidance_scale=3.5, unconditional_conditioning=uncond)
+    assert rel(dec, full) < 1e-5
+    # stochastic_encode (ddim.py:434-449) against its closed form on the schedule's tables
+    x0 = torch.randn(B, 8, 256, 16, generator=torch.Generator().manual_seed(5)).cuda()
+    nz = torch.randn(B, 8, 256, 16, generator=torch.Generator().manual_seed(6))
+    t = torch.tensor([3] * B)
+    enc = s.stochastic_encode(x0, t, noise=nz)
+    want = float(s.ddim_alphas[3]) ** 0.5 * x0.cpu() + float(s.ddim_sqrt_one_minus_alphas[3]) * nz
+    assert rel(enc.cpu(), want) < 1e-6
