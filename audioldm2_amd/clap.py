@@ -502,9 +502,16 @@ class CLAPAudioEmbeddingClassifierFreev2(nn.Module):
         # (global_rows, local_rows) while a prompt-sharded job re-ranks: the reference draws one uniform per row of the GLOBAL
         # candidate batch (audio pass, then text pass); a shard must consume the same draws and keep its rows' decisions
         self.decision_shard = None
-        self.weights_loaded = False   # set by load_state_dict: a randomly initialised re-ranker must not rank silently
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "weights_loaded", True))
+        self.weights_loaded = False   # set by _load_from_state_dict: a randomly initialised re-ranker must not rank silently
         self.eval()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """`weights_loaded` = this load supplied every tensor of THIS module (keys under its own prefix).  A post-hook cannot
+        tell: PyTorch runs post-hooks on every submodule of a parent `load_state_dict(strict=False)` whether or not a key
+        matched, so a checkpoint without `clap.*` would have marked the re-ranker as loaded."""
+        own = self.state_dict()
+        self.weights_loaded = len(own) > 0 and all((prefix + k) in state_dict for k in own)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def tokenizer(self, text):
         """encoders/modules.py:737-745"""

@@ -652,7 +652,7 @@ static int default_attn_mode() {
         };
         int m = parse(getenv("ALDM_ATTN_MMA"));
         if (m == 0) m = parse(getenv("ALDM_MMA"));
-        return m ? m : 3;
+        return m ? m : 2;   // the library default is the fp32-grade mode (bf16x6), like audioldm2_amd.ops.MMA_MODE
     }();
     return v;
 }

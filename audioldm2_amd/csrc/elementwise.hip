@@ -134,11 +134,13 @@ __global__ void ddim_step_indexed_kernel(float* __restrict__ x, const float* __r
 // thread reads the old counter before thread 0 stores the new one)
 __global__ void step_advance_kernel(int* __restrict__ step_idx, const float* __restrict__ t_tab, float* __restrict__ t_cur,
                                     int nt, int steps) {
+    // the counter saturates at the last row: a replay past the end of the run (an extra run_step()) re-reads the last step's
+    // coefficient / noise / timestep rows instead of indexing the tables out of bounds
     const int s = *step_idx + 1;
     const int row = s < steps ? s : steps - 1;
     for (int j = threadIdx.x; j < nt; j += blockDim.x) t_cur[j] = t_tab[(int64_t)row * nt + j];
     __syncthreads();
-    if (threadIdx.x == 0) *step_idx = s;
+    if (threadIdx.x == 0) *step_idx = row;
 }
 
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,

@@ -29,6 +29,10 @@ int igemm_dma_ws_blocks_per_cu(int BM, int BN, int nst, int parts);
 // ... and its loader-wave form (igemm_dma_lw.hip): same grid, twice the waves per block
 int igemm_launch_dma_lw(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_lw_config_ok(int BM, int BN, int nst, int parts);
+// ... and the operand-stationary form for short K (igemm_dma_os.hip): weight slab in registers, 32-row stages of the whole K
+int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
+bool igemm_dma_os_config_ok(int KT, int nst, int parts);
+int igemm_dma_os_default_stages(int KT, int parts);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -256,6 +260,17 @@ static bool dma_ws_eligible(const IgemmK& p, int BM, int BN) {
     return true;
 }
 
+// the operand-stationary DMA kernel (igemm_dma_os.h) runs 1x1 / linear launches whose output row m reads input row m: one tap,
+// stride 1, no padding / upsample / row remap, all of K in one tap, no split-K; the QKV epilogue needs its three segments to be
+// whole 128-column slabs
+static bool dma_os_eligible(const IgemmK& p) {
+    const aldm_igemm_desc& d = p.d;
+    if (d.KH != 1 || d.KW != 1 || d.SH != 1 || d.SW != 1 || d.PH != 0 || d.PW != 0 || d.up_h != 1 || d.up_w != 1) return false;
+    if (d.OH != d.H || d.OW != d.W || d.K != p.Cin || d.K % 32 != 0 || d.out_mul > 0 || d.batch > 1) return false;
+    if (d.epi_mode == ALDM_EPI_QKV && d.qkv_c % 128 != 0) return false;
+    return true;
+}
+
 static bool tile_supported(int BM, int BN) {
     return (BM == 128 && (BN == 128 || BN == 64 || BN == 32)) || (BM == 64 && (BN == 128 || BN == 64));
 }
@@ -355,6 +370,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     p.nst = 0;
     p.ws = 0;
     p.ws_blocks = 0;
+    p.os_rows = 0;
     ALDM_CHECK(d.out_split_act == ALDM_ACT_NONE || (d.out_split_act == ALDM_ACT_LRELU && d.out_split != nullptr &&
                                                    d.epi_mode == ALDM_EPI_PLAIN),
                "aldm_igemm: out_split_act must be ALDM_ACT_NONE or ALDM_ACT_LRELU with a split-image output of the plain epilogue");
@@ -396,11 +412,49 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             return T;
         };
         int splits = 1, nst = 0;
-        const int f_bm = g_force_bm ? g_force_bm : d.hint_bm, f_bn = g_force_bm ? g_force_bn : d.hint_bn;
+        // a tuned hint is keyed by geometry, not by epilogue: one whose tile the QKV / GEGLU epilogue cannot use (tile width not
+        // dividing qkv_c; not 128 columns) is dropped and the cost search below picks the tile — only a FORCED tile fails
+        const bool hint_fits = d.hint_bm > 0 && (!qkv || (d.hint_bn > 0 && d.qkv_c % d.hint_bn == 0)) && (!geglu || d.hint_bn == 128);
+        const int f_bm = g_force_bm ? g_force_bm : (hint_fits ? d.hint_bm : 0), f_bn = g_force_bm ? g_force_bn : d.hint_bn;
         const int f_sp = g_force_bm ? g_force_splits : d.hint_splits;
-        int f_st = g_force_bm ? g_force_stages : d.hint_stages;
+        int f_st = g_force_bm ? g_force_stages : (hint_fits ? d.hint_stages : 0);
         int ws_nst = 0;   // stages in [100, 200): the persistent wave-specialised kernel with a ring of (stages - 100)
-        int lw_nst = 0;   // stages >= 200: igemm_dma_kernel with loader waves, ring of (stages - 200)
+        int lw_nst = 0;   // stages in [200, 300): igemm_dma_kernel with loader waves, ring of (stages - 200)
+        if (f_st >= 300) {
+            // stages >= 300: the operand-stationary kernel, ring of (stages - 300) 32-row stages (300 itself: the deepest ring that
+            // fits).  A launch it cannot run keeps the cost search's tile on igemm_dma_kernel when the request was a tuned hint
+            // (tables are keyed by geometry, not by epilogue) and fails when it was forced.
+            const int KT = d.K / 32;
+            int os_nst = f_st - 300;
+            if (os_nst == 0) os_nst = igemm_dma_os_default_stages(KT, d.split_parts);
+            if (dma_os_eligible(p) && igemm_dma_os_config_ok(KT, os_nst, d.split_parts)) {
+                const char* env_rows_s = getenv("ALDM_OS_ROWS");   // tuning override (tools/os_probe.py): rows per block
+                const int env_rows = env_rows_s ? atoi(env_rows_s) : 0;
+                const int tn = cdiv(d.N, 128);
+                const int stages = cdiv(p.M, 32);
+                const int chunks = std::max(1, device_cus() / tn);   // one block per CU: the largest chunk count that still is one round
+                int rows = cdiv(stages, chunks) * 32;
+                if (env_rows > 0) rows = cdiv(env_rows, 32) * 32;
+                BM = 32;
+                BN = 128;
+                p.tiles_n = tn;
+                p.tiles_m = cdiv(p.M, rows);
+                p.os_rows = rows;
+                p.kt_per_split = nk;
+                p.splits = 1;
+                p.kgroups = 1;
+                p.bx = 1;
+                p.pre = pre;
+                p.dma = 1;
+                p.nst = os_nst;
+                p.ws = 3;
+                p.ws_blocks = 0;
+                return 0;
+            }
+            ALDM_CHECK(!g_force_bm, "aldm_igemm: the operand-stationary DMA kernel cannot run this launch (K = %d, %d stages, %d parts)",
+                       d.K, os_nst, d.split_parts);
+            f_st = 0;
+        }
         if (f_st >= 200) {
             lw_nst = f_st - 200;
             f_st = 0;
@@ -408,7 +462,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             ws_nst = f_st - 100;
             f_st = 0;
         }
-        if (f_bm) {
+        if (f_bm && !(f_bm == 32 && !g_force_bm)) {   // (a hinted 32-row "tile" is an operand-stationary entry that fell back)
             BM = f_bm;
             BN = f_bn;
             nst = f_st > 0 ? f_st
@@ -639,7 +693,9 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     // BX: the 128x128 image leaves room for one block per CU, so that tile takes 8 waves for every prologue
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
                     (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
-    if (p.dma && p.ws == 2) {
+    if (p.dma && p.ws == 3) {
+        rc = igemm_launch_dma_os(d.K / 32, p.nst, d.split_parts, grid, st, p);
+    } else if (p.dma && p.ws == 2) {
         rc = igemm_launch_dma_lw(BM, BN, p.nst, d.split_parts, grid, st, p);
     } else if (p.dma && p.ws) {
         rc = igemm_launch_dma_ws(BM, BN, p.nst, d.split_parts, p.ws_blocks, st, p);

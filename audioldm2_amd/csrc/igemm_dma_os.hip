@@ -1,0 +1,37 @@
+// igemm_dma_os.hip — instantiations of the operand-stationary DMA-fed GEMM (igemm_dma_os.h).
+#include "igemm_dma_os.h"
+
+namespace aldm {
+
+// (k-tiles, ring depth) per image format: what fits 160 KB of LDS next to the 16 KB epilogue staging, and what fits the register
+// file (the weight slab takes 2 KT x NP x 4 VGPRs: 192 at KT = 8 / 288 at KT = 12 with 3-part images, 128 / 192 with 2-part ones)
+bool igemm_dma_os_config_ok(int KT, int nst, int parts) {
+    if (parts == 3) return (KT == 8 && (nst == 2 || nst == 3)) || (KT == 12 && nst == 2);
+    return (KT == 8 && (nst == 2 || nst == 3 || nst == 4)) || (KT == 12 && (nst == 2 || nst == 3));
+}
+
+// the deepest ring that fits: the default when a launch is routed here without an explicit depth
+int igemm_dma_os_default_stages(int KT, int parts) {
+    if (parts == 3) return KT == 8 ? 3 : 2;
+    return KT == 8 ? 4 : 3;
+}
+
+int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+#define ALDM_OS(KT_, NST_, NP_)                                                                                  \
+    if (KT == KT_ && nst == NST_ && parts == NP_) {                                                              \
+        hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_>), grid, dim3(256), 0, st, p);                   \
+        return 0;                                                                                                \
+    }
+    ALDM_OS(8, 2, 3)
+    ALDM_OS(8, 3, 3)
+    ALDM_OS(12, 2, 3)
+    ALDM_OS(8, 2, 2)
+    ALDM_OS(8, 3, 2)
+    ALDM_OS(8, 4, 2)
+    ALDM_OS(12, 2, 2)
+    ALDM_OS(12, 3, 2)
+#undef ALDM_OS
+    return -1;
+}
+
+}  // namespace aldm

@@ -23,8 +23,10 @@ struct IgemmK {
     int pre;                   // PRE_* prologue mode of the descriptor
     int dma;                   // 1: DMA-fed kernel over a pre-split A image (d.a_split)
     int nst;                   // DMA kernel: LDS ring depth of the chosen instantiation
-    int ws;                    // 1: the persistent wave-specialised DMA kernel (igemm_dma_ws.h), ws_blocks blocks
+    int ws;                    // 1: the persistent wave-specialised DMA kernel (igemm_dma_ws.h), ws_blocks blocks; 2: loader waves
+                               // (igemm_dma_lw.h); 3: the operand-stationary kernel (igemm_dma_os.h)
     int ws_blocks;
+    int os_rows;               // operand-stationary kernel: rows per block (a multiple of 32)
 };
 
 enum { PRE_NONE = 0, PRE_AFFINE = 1, PRE_AFFINE_SILU = 2, PRE_LRELU = 3, PRE_GENERIC = 4 };
@@ -130,12 +132,15 @@ __device__ __forceinline__ void split8_to_parts(const float (&x)[8], u32x4 (&par
 //   v = act(acc + bias + rowbias); v = alpha*(v + res); out = accumulate ? out + v : v
 // `lds` = the block's LDS (free: every wave is past its last read of the K-loop image); wave w stages in
 // lds[w * 32 * (NT*32+4) ...].  wm / wn = this wave's position in the block's wave grid.
-template <int MT, int NT>
+// PAD: extra floats per staged row (default 4: the float4 read-back is conflict free and the two half waves' writes hit
+// different banks; 0 = unpadded, 4 KB per wave at NT = 1 — the half waves' ds_write_b32 then conflict 2-way, which costs a
+// ds_write_b32 nothing (MI355X_MICROARCH.md, LDS) — for the operand-stationary kernel, whose ring leaves exactly 16 KB).
+template <int MT, int NT, int PAD = 4>
 __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT][NT], float* lds, int m0, int n0,
                                                int wave, int wm, int wn, int lane, int z, int split) {
     const aldm_igemm_desc& d = p.d;
     const bool epi_st = (ALDM_DMA_ABLATE & 64) ? p.M == -12345 : true;   // (ablation builds: compute, never store)
-    constexpr int SP = NT * 32 + 4;   // staging row pitch (floats); +4 keeps 16-byte alignment
+    constexpr int SP = NT * 32 + PAD;   // staging row pitch (floats); a multiple of 4 keeps 16-byte alignment
     constexpr int C4 = NT * 8;        // float4 per staged row
     constexpr int RPI = 64 / C4;      // rows covered by one wave-wide float4 read
     constexpr int IT = 32 / RPI;      // reads per 32-row slab

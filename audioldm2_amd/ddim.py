@@ -364,6 +364,10 @@ class DDIMSampler(object):
         total_steps = ts.shape[0]
         time_range = np.flip(ts)
         use_cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.0)
+        if total_steps == 0:
+            # `timesteps` <= one DDIM interval: the reference's loop runs zero iterations and returns x_T (ddim.py:198-262)
+            img = (self._drawer(tuple(shape))() if x_T is None else x_T.detach().float().cpu()).to(dev).contiguous()
+            return img, {"x_inter": [img], "pred_x0": [img]}
 
         # RNG contract R: x_T first, then the per-step draws, all from the host generator in the
         # reference's order; the per-step draws are streamed (see _NoiseFeed)
@@ -453,7 +457,13 @@ class DDIMSampler(object):
         ent["t_cur"].copy_(ent["t_tab"][0])
         x_cur, pred_x0 = ent["x_cur"], ent["pred_x0"]
         # the per-step draws are streamed by a drawer thread straight into the graph's static noise buffer (see _NoiseFeed)
-        feed = _NoiseFeed(draw, total_steps, tuple(shape), mask is not None, temperature, dev, noise_buf=ent["noise_all"])
+        # While a run is in flight ONLY the drawer thread may consume torch's default CPU generator (it runs up to three 8-step
+        # chunks ahead).  A callback that draws from that generator itself declares it (`callback.uses_rng = True`): the draws
+        # then stay on the launching thread, one step at a time, sequenced with the callback exactly as in the reference
+        # (ALDM_NOISE_THREAD=0 forces the unthreaded feed for every run).
+        cb_rng = any(getattr(f, "uses_rng", False) for f in (callback, img_callback) if f is not None)
+        feed = _NoiseFeed(draw, total_steps, tuple(shape), mask is not None, temperature, dev, noise_buf=ent["noise_all"],
+                          **({"threaded": False, "chunk": 1} if cb_rng else {}))
         feed.produce_next()
         qn = feed.qnoise
         run_step = ent["run_step"]
@@ -470,7 +480,7 @@ class DDIMSampler(object):
                     # after the eager first step: the K/V projections of this run's contexts exist; the cache entry owns
                     # them from here on (the graph captured at the next step reads these very buffers)
                     ent["kv"] = unet.collect_context_kv(ent["prepared"]["ctxs"])
-                if opens_chunk:
+                if opens_chunk and not cb_rng:
                     feed.produce_next()  # (unthreaded mode only) draw + upload the NEXT chunk while the GPU works on this one
                 if callback:
                     callback(i)

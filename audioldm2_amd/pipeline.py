@@ -40,6 +40,13 @@ def instantiate_from_config(config: dict):
     return get_obj_from_str(config["target"])(**config.get("params", dict()))
 
 
+def _pcm16(x):
+    """float waveform -> 16-bit PCM the way libsndfile (the reference's `soundfile.write`, utils.py:53-77) converts it: scaled by
+    0x7FFF and rounded (lrintf).  libsndfile does not clip by default; out-of-range samples are clipped here instead of wrapping
+    (the one deliberate deviation — the reference normalises its waveforms to |x| <= 0.5 before saving)."""
+    return np.clip(np.rint(np.asarray(x, dtype=np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+
+
 def seed_everything(seed):
     """pipeline.py:20-31"""
     random.seed(seed)
@@ -637,7 +644,7 @@ class LatentDiffusion(nn.Module):
                 raise NotImplementedError
             x = np.asarray(waveform[i, 0], dtype=np.float64)
             x = (x / np.max(np.abs(x))) * 0.8   # normalize the energy of the generation output
-            wavfile.write(path, int(self.sampling_rate), np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16))
+            wavfile.write(path, int(self.sampling_rate), _pcm16(x))
             paths.append(path)
         return paths
 
@@ -946,7 +953,7 @@ def save_wave(waveform, savepath, name="outwav", samplerate=16000):
         path = os.path.join(savepath, fname)
         print("Save audio to %s" % path)
         x = np.asarray(waveform[i, 0], dtype=np.float64)
-        wavfile.write(path, int(samplerate), np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16))
+        wavfile.write(path, int(samplerate), _pcm16(x))
         paths.append(path)
     return paths
 

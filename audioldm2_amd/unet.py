@@ -226,7 +226,9 @@ class BasicTransformerBlock(nn.Module):
         n = ops.layernorm(h, *pk["ln"][0], split_out=so)
         # self-attention over operands the projection's epilogue pre-splits (round 3): k as a split image, v transposed per key
         # tile — when the token count is a whole number of 32-key tiles (every UNet level of every config)
-        pre = so is not None and PRESPLIT_ATTENTION and h.shape[1] % 32 == 0
+        # (... and the width is a whole number of 64-column tiles — an even head count — and the projection has no bias: what
+        # ALDM_EPI_QKV requires; anything else takes the fp32 K / V path)
+        pre = so is not None and PRESPLIT_ATTENTION and h.shape[1] % 32 == 0 and C % 64 == 0 and pk["qkv1"].bias is None
         if pre:
             q, kimg, vtimg = ops.linear_qkv(n, pk["qkv1"], self.heads, h.shape[1])
             a = ops.attention_presplit(q, kimg, vtimg, self.heads, split_out=so)
@@ -238,7 +240,7 @@ class BasicTransformerBlock(nn.Module):
         if context is None:
             if pk["qkv2"] is None:
                 raise RuntimeError("attn2 was built with a context_dim but no context was provided")
-            if pre:
+            if pre and pk["qkv2"].bias is None:
                 q, kimg, vtimg = ops.linear_qkv(n, pk["qkv2"], self.heads, h.shape[1])
                 a = ops.attention_presplit(q, kimg, vtimg, self.heads, split_out=so)
             else:
@@ -441,6 +443,15 @@ class UNetModel(nn.Module):
         for m in self.modules():
             if hasattr(m, "_pk"):
                 m._pk = None
+            if hasattr(m, "_kv"):
+                m._kv = None
+
+    def drop_step_caches(self):
+        """Drop what depends on the matrix-core mode but not on the weights: the captured step graph and the cached
+        cross-attention K/V projections (call after ops.set_mma(); the packed weights keep both split images)."""
+        from .ddim import drop_graph_entries
+        drop_graph_entries(self._graph_cache)
+        for m in self.modules():
             if hasattr(m, "_kv"):
                 m._kv = None
 

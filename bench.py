@@ -4,19 +4,29 @@
 One "step" = one whole job of the hot path over one batch of synthetic prompts:
   sample_log (200 DDIM steps, CFG 3.5, eta 1.0) -> VAE decode -> HiFi-GAN -> waveform on the host
 for `audioldm2-full`, batch 8 prompts per GPU, 10.24 s of 16 kHz audio per prompt (BASELINE.json
-configs[1]); n_candidate_gen_per_text = 1; conditioners (out of scope) are synthetic and excluded.
+configs[1]); n_candidate_gen_per_text = 1; conditioning resident in HBM (synthetic), conditioners timed separately.
 metric = audio-seconds / second (whole job, all GPUs).  Weak scaling: per-GPU batch fixed.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant igemm kernel and the attention
-kernel, measured live with events on the launch stream; the cost of an empty event pair, measured in the same run,
-is subtracted from every bracketed launch so the durations compare with rocprofv3's kernel-only ones), `strict`
-(the same job re-run in the same invocation with fp32-grade bf16x6 products: value, UNet step, roofline), `configs`
-(N = 1 only: the other three BASELINE configurations at batch 8, `--configs-steps` timed jobs each: value, UNet step, tail) and
-`cpu_baseline` (the CPU oracle = the reference's arithmetic on the host cores, bounded sample).  `dtype` and every
-`*_frac_of_*_peak` name the arithmetic that actually ran.
+The headline runs in the library's DEFAULT product mode, "bf16x6": fp32 storage / accumulation, every product evaluated as 6 bf16
+MFMA partial products of exact 3-part operand splits — fp32-grade (2.4e-7 rms per contraction; the fp32 MFMA itself: 2.1e-7), i.e.
+not narrower than the reference's fp32 multiply.  Prints ONE JSON line on rank 0 with the contract keys plus
+  `roofline`      dominant igemm instantiation + the attention kernel, measured live with events on the launch stream (the cost of
+                  an empty event pair, measured in the same run, is subtracted so the durations compare with rocprofv3's), HBM
+                  traffic from profiles/r04_pmc_traffic_<mode>.json while its source hash matches the running kernels;
+  `roofline_tail` VAE decode and HiFi-GAN;
+  `fast`          the same job re-run in the opt-in "bf16x3" mode (16-bit operand significands: NARROWER than fp32 — a named
+                  sub-record, never the headline);
+  `configs`       N = 1 only: the other three BASELINE configurations at batch 8 (value, UNet step, tail), headline mode;
+  `conditioners`  N = 1 only: what the job above leaves out — the conditioner stack of every configuration at batch 8 and its real
+                  geometry (FLAN-T5-large x2, CLAP text tower, GPT-2 AudioMAE-token generator incl. the speech model's 512
+                  tokens, VITS phoneme encoder; random-init weights, stub tokenizers): ms per batch and audio-s/s including them;
+  `api_default`   N = 1 only: the public API's default n_candidate_gen_per_text = 3 (pipeline.py:181-193): 3 x the UNet work
+                  plus CLAP re-ranking (HTSAT-base + RoBERTa-base), delivered audio-s/s;
+  `cpu_baseline`  the CPU oracle = the reference's arithmetic on the host cores, bounded sample.
+`dtype` and every `*_frac_of_*_peak` name the arithmetic that actually ran.
 """
 import argparse
 import json
@@ -39,7 +49,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, den
 # matrix-core roofline is the dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16, ~2500 TFLOP/s) / 6
 PEAK_BF16X6_TFLOPS = round(2500.0 / 6.0, 1)
 PEAK_BF16X3_TFLOPS = round(2500.0 / 3.0, 1)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+def traffic_json(mode):
+    """PMC traffic file of the product mode (tools/pmc_traffic.py, stamped with the kernel-source hash)."""
+    return os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{mode}.json")
 MODE_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}
 MODE_DTYPE = {
     "f32": "f32 (storage, accumulate and products: fp32 MFMA)",
@@ -97,15 +109,111 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-probe", action="store_true")
     ap.add_argument("--cpu-ddim-steps", type=int, default=8)
-    ap.add_argument("--no-strict", action="store_true", help="skip the bf16x6 (fp32-grade) re-run reported under `strict`")
+    ap.add_argument("--no-fast", "--no-strict", dest="no_fast", action="store_true",
+                    help="skip the bf16x3 (16-bit operand significands) re-run reported under `fast`")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations reported under `configs`")
-    ap.add_argument("--configs-steps", type=int, default=3, help="timed jobs per other configuration")
-    ap.add_argument("--strict-steps", type=int, default=2, help="timed jobs of the strict re-run")
+    ap.add_argument("--configs-steps", type=int, default=1, help="timed jobs per other configuration (after one warm-up job)")
+    ap.add_argument("--fast-steps", type=int, default=2, help="timed jobs of the fast re-run")
+    ap.add_argument("--no-conditioners", action="store_true", help="skip the conditioner stacks reported under `conditioners`")
+    ap.add_argument("--no-api-default", action="store_true", help="skip the n_candidate_gen_per_text = 3 job (`api_default`)")
     return ap.parse_args()
 
 
-def mode_strict_wanted(args, aops):
-    return not args.no_strict and aops.MMA_MODE == "bf16x3" and aops.use_dma()
+def fast_wanted(args, aops):
+    return not args.no_fast and aops.MMA_MODE == "bf16x6" and aops.use_dma()
+
+
+class _StubRobertaTokenizer:
+    """RobertaTokenizer.from_pretrained("roberta-base") as CLAP calls it (encoders/modules.py:737-745: padding="max_length",
+    max_length=512) — the Hub is unreachable offline: deterministic ids from the prompt's characters, <s> = 0 ... </s> = 2, pad 1."""
+
+    def __call__(self, texts, padding=None, truncation=None, max_length=512, return_tensors=None):
+        texts = [texts] if isinstance(texts, str) else list(texts)
+        T = max_length or 512
+        ids = torch.ones(len(texts), T, dtype=torch.long)
+        mask = torch.zeros(len(texts), T, dtype=torch.long)
+        for b, t in enumerate(texts):
+            row = [0] + [3 + (ord(ch) * 7 + i) % 40000 for i, ch in enumerate(t.split() and t)][: T - 2][:24] + [2]
+            ids[b, : len(row)] = torch.tensor(row)
+            mask[b, : len(row)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+class _StubT5Tokenizer:
+    """AutoTokenizer.from_pretrained("google/flan-t5-large") as FlanT5HiddenState calls it (encoders/modules.py:175-181): ~one id
+    per 3 characters, EOS = 1 last, right padded with 0."""
+
+    def __call__(self, prompt, max_length=128, padding=True, truncation=True, return_tensors="pt"):
+        import types
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        rows = [[3 + (ord(ch) * 11 + i) % 30000 for i, ch in enumerate(p_[::3])][: max_length - 1] + [1] for p_ in prompt]
+        T = max(len(r) for r in rows)
+        ids = torch.zeros(len(rows), T, dtype=torch.long)
+        mask = torch.zeros(len(rows), T, dtype=torch.long)
+        for b, r in enumerate(rows):
+            ids[b, : len(r)] = torch.tensor(r)
+            mask[b, : len(r)] = 1
+        return types.SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+
+PROMPT = "A dog barks twice in the distance while steady rain falls on a tin roof and a car passes by"
+
+
+def _set_stub_tokenizers(module):
+    from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2
+    from audioldm2_amd.t5 import FlanT5HiddenState
+    for m in module.modules():
+        if isinstance(m, CLAPAudioEmbeddingClassifierFreev2):
+            m.tokenize = _StubRobertaTokenizer()
+        elif isinstance(m, FlanT5HiddenState):
+            m.tokenizer = _StubT5Tokenizer()
+
+
+def conditioner_probe(model_name, B):
+    """The conditioner stack `generate_batch` runs before sampling (ddpm.py:1056-1120) for `model_name` at batch B
+    and its REAL geometry: the reference's cond_stage_config with our targets (pipeline.hip_cond_stage_config), random-init
+    weights, stub tokenizers.  Returns the wall time of learned + unconditional conditioning per batch (ms, best of 3 after a
+    warm-up; host tokenisation and H2D included)."""
+    from audioldm2_amd.pipeline import hip_cond_stage_config, instantiate_from_config, make_batch_for_text_to_audio
+    from audioldm2_amd.phoneme import phoneme_ids
+    torch.manual_seed(7)
+    cfgs = hip_cond_stage_config(model_name)
+    models = {}
+    for k, c in cfgs.items():
+        m = instantiate_from_config(c).cuda().eval()
+        _set_stub_tokenizers(m)
+        models[k] = (m, c["cond_stage_key"])
+    batch = make_batch_for_text_to_audio(PROMPT, batchsize=B)
+    if "-speech-" in model_name:   # a 10 s utterance: ~200 phonemes of the 310-position window
+        ph = torch.randint(1, 183, (B, 310), generator=torch.Generator().manual_seed(3))
+        ph[:, 200:] = 0
+        batch["phoneme_idx"] = ph
+    if "48k" in model_name:
+        batch["log_mel_spec"] = torch.zeros((B, 1024, 256))
+        batch["fbank"] = batch["log_mel_spec"]
+
+    def run():
+        out = {}
+        for k, (m, key) in models.items():
+            xc = batch if key == "all" else batch[key]
+            out[k] = m(xc)
+            out[k + "/uncond"] = m.get_unconditional_condition(B)
+        torch.cuda.synchronize()
+        return out
+    run()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    del models
+    torch.cuda.empty_cache()
+    what = {"audioldm_48k": "CLAP text tower (RoBERTa-base, 512 positions)",
+            "audioldm2-speech-gigaspeech": "CLAP text tower + VITS phoneme encoder (310 positions) + GPT-2 generator, 512 AudioMAE "
+                                           "tokens (KV-cached, graph-replayed decode)"}.get(
+        model_name, "CLAP text tower + FLAN-T5-large encoder x2 (inner and outer instance, like the reference) + GPT-2 generator, "
+                    "8 AudioMAE tokens")
+    return {"ms_per_batch": round(min(ts), 2), "batch": B, "what": what}
 
 
 def roofline_probe(ld, batch, B):
@@ -162,6 +270,7 @@ def roofline_probe(ld, batch, B):
     # HBM traffic of the same kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, separate runs) of this
     # command, committed under profiles/ (tools/pmc_traffic.py); null when that file is absent
     traffic, traffic_src = None, None
+    TRAFFIC_JSON = traffic_json(ops.MMA_MODE)
     if os.path.exists(TRAFFIC_JSON):
         from audioldm2_amd.lib import source_hash
         with open(TRAFFIC_JSON) as f:
@@ -177,7 +286,7 @@ def roofline_probe(ld, batch, B):
                            "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}
-    dma = kname.startswith(("igemm_dma_kernel", "igemm_dma_ws_kernel", "igemm_dma_lw_kernel"))
+    dma = kname.startswith(("igemm_dma_kernel", "igemm_dma_ws_kernel", "igemm_dma_lw_kernel", "igemm_dma_os_kernel"))
     bx = kname.endswith("true>") or dma                # bf16-split instantiations
     x3 = dma and parts_of.get(kname) == 2              # 2-part images: 3 partial products
     peak = (PEAK_BF16X3_TFLOPS if x3 else PEAK_BF16X6_TFLOPS) if bx else PEAK_F32_MFMA_TFLOPS

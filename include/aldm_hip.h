@@ -16,9 +16,9 @@
  *     reference's plain-exception convention (e.g. openaimodel.py:858-860 asserts).
  *   - operands, accumulators and every stored tensor are IEEE fp32; HOW an fp32 x fp32 product of a contraction is
  *     evaluated depends on the matrix-core mode: "f32" = v_mfma_f32_32x32x2_f32 (exact fp32 products,
- *     bit-identical to an fmaf chain); "bf16x6" = 6 bf16 MFMA partial products of exact 3-part operand splits (fp32
- *     grade, 2.4e-7 rms vs fp64); "bf16x3" (the DEFAULT for launches over pre-split operands and for attention) = 3
- *     partial products of (hi, mid) parts rounded to nearest: 16 significant bits per operand, 4.4e-6 rms per contraction.
+ *     bit-identical to an fmaf chain); "bf16x6" (the DEFAULT) = 6 bf16 MFMA partial products of exact 3-part operand
+ *     splits (fp32 grade, 2.4e-7 rms vs fp64); "bf16x3" (opt-in fast mode for launches over pre-split operands and for
+ *     attention) = 3 partial products of (hi, mid) parts rounded to nearest: 16 significant bits per operand, 4.4e-6 rms.
  */
 #ifndef ALDM_HIP_H
 #define ALDM_HIP_H
@@ -193,8 +193,11 @@ int aldm_igemm_plan_stages(const aldm_igemm_desc* d);
 void aldm_igemm_force(int bm, int bn, int splits, int kgroups);
 /* ... and the LDS ring depth of the DMA-fed kernel (a_split descriptors): 128x128 {2,3}, 64x128 / 128x64 {2,4},
  * 64x64 {2,3}; 0 = default for the tile; 100 + depth = the persistent wave-specialised kernel (64x128 {3,4,5}, 128x64
- * {3,4}, 64x64 {4,6} on 2-part images; 64x128 / 128x64 {2,3}, 64x64 {3,4} on 3-part images) — a forced launch it cannot
- * run fails.  aldm_igemm_force() resets it to 0.                                                              */
+ * {3,4}, 64x64 {4,6} on 2-part images; 64x128 / 128x64 {2,3}, 64x64 {3,4} on 3-part images); 200 + depth = the loader-wave
+ * form; 300 + depth = the OPERAND-STATIONARY kernel for short K (csrc/igemm_dma_os.h: 1x1 / linear launches with K = 256 or
+ * 384, the weight slab of a 128-column block held in registers, A streamed in 32-row stages of the whole K; depth 2-3 on
+ * 3-part images (K = 384: 2), 2-4 on 2-part ones; 300 = the deepest ring that fits; forced with bm = 32, bn = 128) — a forced
+ * launch one of them cannot run fails, a hinted one falls back to aldm_igemm's own choice.  aldm_igemm_force() resets it to 0. */
 void aldm_igemm_force_stages(int stages);
 /* Tuning override (tests / tools): bit mask of the block tiles that run with 8 instead of 4 wavefronts per
  * tile on this thread (1: 128x128, 2: 64x128, 4: 128x64 — GroupNorm-prologue launches; 8: 128x128 launches
@@ -292,7 +295,7 @@ int aldm_attention_d32_presplit(const float* q, const void* k_split, const void*
                                 int parts, int B, int heads, int Lq, int Lk, int ldq, int ldo, float scale, void* stream);
 /* Matrix-core path of aldm_attention_d32, PROCESS wide: 1 = fp32 MFMA, 2 = "bf16x6" (both products as 6 bf16 partial
  * products of exact 3-part operand splits), 3 = "bf16x3" ((hi, mid) rounded to nearest, 3 partial products), -1 =
- * default: $ALDM_ATTN_MMA if set, else the engine's $ALDM_MMA, else bf16x3 ("f32" | "bf16x6" | "bf16x3"; anything else is
+ * default: $ALDM_ATTN_MMA if set, else the engine's $ALDM_MMA, else bf16x6 ("f32" | "bf16x6" | "bf16x3"; anything else is
  * reported on stderr and ignored).  Returns the previous mode; other values only query.                         */
 int aldm_attention_mma(int mode);
 /* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,

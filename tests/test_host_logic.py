@@ -536,7 +536,7 @@ def test_save_wave_names_files_like_the_reference(tmp_path):
         assert ours == ref_paths
     sr, data = wavfile.read(ours[0])
     assert sr == 16000 and data.dtype == np.int16 and data.shape == (1600,)
-    assert np.abs(data / 32768.0 - cases_[0][0][0, 0]).max() <= 0.5 / 32768 + 1e-9
+    assert np.abs(data / 32767.0 - cases_[0][0][0, 0]).max() <= 0.5 / 32767 + 1e-9   # libsndfile's float -> PCM16 scale is 0x7FFF
 
 
 def test_phoneme_ids_and_batch_layout_match_the_reference():
@@ -583,3 +583,41 @@ def test_save_waveform_names_and_normalises_like_the_reference(tmp_path):
     assert sr == 16000 and abs(np.abs(d).max() / 32768.0 - 0.8) < 1e-4
     with pytest.raises(NotImplementedError):
         LatentDiffusion.save_waveform(me, w, str(tmp_path), 3)
+
+
+def test_reranker_without_clap_weights_is_flagged_and_warned():
+    """a checkpoint without `clap.*` entries, loaded through the PARENT with strict=False, must leave the
+    re-ranker marked as never loaded (PyTorch runs load_state_dict post-hooks on every submodule whether or not a key matched), and
+    `_check_candidates` must warn before ranking with a randomly initialised model."""
+    import warnings
+    from types import SimpleNamespace
+    from audioldm2_amd import clap
+    from audioldm2_amd.pipeline import LatentDiffusion
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.hot = torch.nn.Linear(4, 4)
+            self.clap = clap.CLAPAudioEmbeddingClassifierFreev2(embed_mode="audio", unconditional_prob=0.0, sampling_rate=16000,
+                                                                config=cases.clap_text_test_config(),
+                                                                audio_config=cases.htsat_test_config())
+    m = Parent()
+    assert m.clap.weights_loaded is False
+    full = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict({k: v for k, v in full.items() if not k.startswith("clap.")}, strict=False)
+    assert m.clap.weights_loaded is False, "a load that supplied no clap.* tensor marked the re-ranker as loaded"
+    me = SimpleNamespace(clap=m.clap)
+    with pytest.warns(UserWarning, match="randomly initialised"):
+        LatentDiffusion._check_candidates(me, 2, {"input_ids": None})
+    m.load_state_dict(full, strict=False)
+    assert m.clap.weights_loaded is True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        LatentDiffusion._check_candidates(SimpleNamespace(clap=m.clap), 2, {"input_ids": None})
+    # a direct load of the module itself counts too, a partial one does not
+    own = {k: v.clone() for k, v in m.clap.state_dict().items()}
+    fresh = Parent().clap
+    fresh.load_state_dict(dict(list(own.items())[:-1]), strict=False)
+    assert fresh.weights_loaded is False
+    fresh.load_state_dict(own)
+    assert fresh.weights_loaded is True

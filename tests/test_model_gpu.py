@@ -23,7 +23,7 @@ MOD_TOL = 2e-4
 
 def batch_tol():
     """Agreement of the same computation at two batch sizes: the launches pick different tiles / split-K / attention
-    variants, i.e. different fp32 summation orders (1e-7-level differences).  In the default bf16x3 mode those move the
+    variants, i.e. different fp32 summation orders (1e-7-level differences).  In the bf16x3 mode those move the
     round-to-nearest (hi, mid) operand splits of later layers by an ulp of `mid` here and there, so the two runs agree to
     that mode's own noise floor (per-GEMM 4e-6 rms) rather than to 1e-5."""
     from audioldm2_amd import ops
@@ -32,6 +32,20 @@ def batch_tol():
 
 def gold(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+# The product modes the parity tests pin END TO END: "bf16x6" — the library default, fp32-grade, the mode
+# bench.py's headline is measured in — and "bf16x3", the opt-in fast mode behind bench.py's `fast` sub-record.  Tests without the
+# parameter run the default.
+MODES = ["bf16x6", "bf16x3"]
+
+
+@pytest.fixture(params=MODES)
+def mma(request):
+    from audioldm2_amd import ops
+    prev = ops.set_mma(request.param)
+    yield request.param
+    ops.set_mma(prev)
 
 
 def rel(a, b):
@@ -77,13 +91,13 @@ def cu(x):
     ("unet_film_tiny", cases.UNET_FILM_TINY, 2, 8, 16, 12),
     ("unet_full", cases.UNET_FULL, 1, 256, 16, 32),
 ])
-def test_unet_matches_reference_fixture(name, cfg, B, H, W, t5):
+def test_unet_matches_reference_fixture(name, cfg, B, H, W, t5, mma):
     from audioldm2_amd.unet import UNetModel
     m = load_det(UNetModel(**cfg))
     x, t, ctxs, masks, y = cases.unet_inputs(cfg, B, H, W, t5)
     out = m(x.cuda(), t.cuda(), y=cu(y), context_list=cu(ctxs), context_attn_mask_list=cu(masks))
     e = rel(out, gold(name)["out"])
-    report(f"{name}: max-norm rel err vs reference fixture {e:.2e}")
+    report(f"{name} [{mma}]: max-norm rel err vs reference fixture {e:.2e}")
     assert e < MOD_TOL
 
 
@@ -235,11 +249,20 @@ def ld():
     return _build_ld()
 
 
+@pytest.fixture
+def ld_mode(ld, mma):
+    """The module's LatentDiffusion with the product mode switched: the captured step graph and the cached cross-attention
+    K/V projections belong to a mode, the packed weights keep one split image per mode."""
+    ld.model.diffusion_model.drop_step_caches()
+    yield ld, mma
+    ld.model.diffusion_model.drop_step_caches()
+
+
 # Waveform tolerance (VERDICT r2 "weak" #1): north_star's "within 1e-3 rms" is read against what separates two DIFFERENT
 # samples — every fixture stores `wave_between_rms`, the rms difference between the waveforms of two unrelated samples on
 # these (random-init) weights — so a pass means "1000x closer to the reference than another sample would be", not merely
-# "smaller than a constant the vocoder's biases already satisfy".  All parity here is on random-init weights, default mode
-# (bf16x3 products) unless $ALDM_MMA says otherwise.
+# "smaller than a constant the vocoder's biases already satisfy".  All parity here is on random-init weights, in the library
+# default mode (bf16x6, fp32-grade) unless a test is parametrised over MODES or $ALDM_MMA says otherwise.
 WAVE_REL_TO_BETWEEN = 1e-3
 
 
@@ -281,28 +304,31 @@ def _generate(ld, B, steps):
     return rec
 
 
-def test_e2e_5step_matches_reference_generate_batch(ld):
+def test_e2e_5step_matches_reference_generate_batch(ld_mode):
     """Whole path vs the real LatentDiffusion.generate_batch fixture (B=2, 5 steps, CFG 3.5, seed 42):
-    RNG contract, CFG batching with padded/masked contexts, DDIM update, VAE decode, vocoder."""
+    RNG contract, CFG batching with padded/masked contexts, DDIM update, VAE decode, vocoder.  Both product modes."""
+    ld, mode = ld_mode
     g = gold("e2e_full_5step_b2")
     out = _generate(ld, 2, 5)
     assert out["wave"].dtype == np.float32 and out["wave"].shape == (2, 1, 163872)
-    errs = _report("e2e 5 steps B=2", out, g)
+    errs = _report(f"e2e 5 steps B=2 [{mode}]", out, g)
     assert errs["latent"][0] / errs["latent"][1] < 1e-4
     assert errs["mel"][0] / errs["mel"][1] < 1e-4
     _assert_wave(errs["wave"][0], g, "e2e 5 steps")
 
 
-def test_e2e_5step_batch8_matches_reference_generate_batch(ld):
+def test_e2e_5step_batch8_matches_reference_generate_batch(ld_mode):
     """BASELINE config 2's batch (8 prompts) end to end against the real reference's generate_batch (5 steps, CFG 3.5, seed
-    42): the global-batch noise draws, the 16-sample CFG pass, per-sample masks (half the batch masks its last 8 T5 keys)."""
+    42): the global-batch noise draws, the 16-sample CFG pass, per-sample masks (half the batch masks its last 8 T5 keys).
+    Both product modes: this is the geometry (and therefore the tuned-table instantiations) bench.py's headline runs."""
+    ld, mode = ld_mode
     g = gold("e2e_full_5step_b8")
     out = _generate(ld, 8, 5)
     assert out["wave"].shape == (8, 1, int(g["wave_len"]))
     el = rms(out["latent"].double().cpu().numpy() - g["latent"]) / rms(g["latent"])
     eh = rms(out["wave"][..., :32768].astype(np.float64) - g["wave_head"])
     ed = rms(out["wave"][..., ::16].astype(np.float64) - g["wave_dec"])
-    report(f"e2e 5 steps B=8: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} / between-sample "
+    report(f"e2e 5 steps B=8 [{mode}]: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} / between-sample "
            f"{float(g['wave_between_rms']):.3e}")
     assert el < 1e-4
     _assert_wave(max(eh, ed), g, "e2e 5 steps B=8")
@@ -338,13 +364,14 @@ def test_cached_step_graph_is_refreshed_with_new_conditioning(ld):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "e2e_full_200step_b1.npz")), reason="200-step fixture absent")
-def test_e2e_200step_waveform_within_north_star_tolerance(ld):
+def test_e2e_200step_waveform_within_north_star_tolerance(ld_mode):
     """BASELINE config 1 (1 prompt, 10 s, 200 DDIM steps, CFG 3.5, seed 42) against the reference's
     CPU run: latent and mel within 1e-4 relative after 400 dependent UNet evaluations, waveform rms error < 1e-3 (north_star)
     AND < 1e-3 of the distance between two unrelated samples' waveforms."""
+    ld, mode = ld_mode
     g = gold("e2e_full_200step_b1")
     out = _generate(ld, 1, 200)
-    errs = _report("e2e 200 steps B=1", out, g)
+    errs = _report(f"e2e 200 steps B=1 [{mode}]", out, g)
     assert errs["latent"][0] / errs["latent"][1] < 1e-4
     assert errs["mel"][0] / errs["mel"][1] < 1e-4
     _assert_wave(errs["wave"][0], g, "e2e 200 steps")
@@ -483,13 +510,27 @@ def test_other_baseline_configs_run_end_to_end(model_name, wave_len):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("fixture,B,steps", [("e2e_48k_2step_b1", 1, 2), ("e2e_48k_20step_b2", 2, 20)])
-def test_e2e_48k_matches_reference_generate_batch(fixture, B, steps):
+@pytest.mark.parametrize("fixture,B,steps,mode", [("e2e_48k_2step_b1", 1, 2, None), ("e2e_48k_20step_b2", 2, 20, None),
+                                                   ("e2e_48k_5step_b8", 8, 5, "bf16x6"), ("e2e_48k_5step_b8", 8, 5, "bf16x3")])
+def test_e2e_48k_matches_reference_generate_batch(fixture, B, steps, mode):
     """BASELINE config 3 (audioldm_48k) end to end against the REAL reference's generate_batch fixtures
-    (B=1, 2 DDIM steps and B=2, 20 steps; CFG 3.5, seed 42): FiLM-conditioned UNet, 4-level VAE decoder, 48 kHz HiFi-GAN."""
+    (B=1, 2 DDIM steps; B=2, 20 steps; and — VERDICT r3 next #1b — B=8, 5 steps = the bench batch, in both product modes, so the
+    instantiations the tuned tables pick for 16-sample passes are the ones compared; CFG 3.5, seed 42): FiLM-conditioned UNet,
+    4-level VAE decoder, 48 kHz HiFi-GAN."""
+    from audioldm2_amd import ops
     from audioldm2_amd.pipeline import build_model, seed_everything
     if not os.path.exists(os.path.join(GOLD, fixture + ".npz")):
         pytest.skip(f"{fixture} absent")
+    prev = ops.set_mma(mode) if mode else None
+    try:
+        _e2e_48k(fixture, B, steps, mode or ops.MMA_MODE)
+    finally:
+        if prev:
+            ops.set_mma(prev)
+
+
+def _e2e_48k(fixture, B, steps, mode):
+    from audioldm2_amd.pipeline import build_model, seed_everything
     g = gold(fixture)
     m = build_model(model_name="audioldm_48k")
     with open(os.path.join(GOLD, "e2e48k_statedict_keys.json")) as f:
@@ -512,7 +553,7 @@ def test_e2e_48k_matches_reference_generate_batch(fixture, B, steps):
     el = rms(rec["latent"].double().cpu().numpy() - g["latent"]) / rms(g["latent"])
     eh = rms(wave[..., :32768].astype(np.float64) - g["wave_head"])
     ed = rms(wave[..., ::16].astype(np.float64) - g["wave_dec"])
-    report(f"48k e2e {steps} steps B={B}: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} "
+    report(f"48k e2e {steps} steps B={B} [{mode}]: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} "
            f"/ rms_ref {float(g['wave_rms']):.3e} / between-sample {float(g['wave_between_rms']):.3e}")
     assert el < 1e-4
     _assert_wave(max(eh, ed), g, fixture)

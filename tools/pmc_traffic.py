@@ -19,7 +19,7 @@ def collect(root, counter):
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] != counter:
                     continue
-                m = re.search(r"igemm(?:_dma)?_kernel<[^>]*>", r["Kernel_Name"])
+                m = re.search(r"igemm(?:_dma(?:_lw|_ws|_os)?)?_kernel<[^>]*>", r["Kernel_Name"])
                 if not m:
                     continue
                 a = acc[m.group(0)]
