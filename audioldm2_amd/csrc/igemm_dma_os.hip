@@ -3,8 +3,9 @@
 
 namespace aldm {
 
-// (k-tiles, ring depth) per image format: what fits 160 KB of LDS next to the 16 KB epilogue staging, and what fits the register
-// file (the weight slab takes 2 KT x NP x 4 VGPRs: 192 at KT = 8 / 288 at KT = 12 with 3-part images, 128 / 192 with 2-part ones)
+// (k-tiles, ring depth) per image format: what fits 160 KB of LDS next to the 8 KB epilogue staging; the weight slab takes
+// KT x NP x 4 VGPRs per wave (96 at KT = 8 / 144 at KT = 12 with 3-part images, 64 / 96 with 2-part ones) of the 256 a wave has at
+// two waves per SIMD
 bool igemm_dma_os_config_ok(int KT, int nst, int parts) {
     if (parts == 3) return (KT == 8 && (nst == 2 || nst == 3)) || (KT == 12 && nst == 2);
     return (KT == 8 && (nst == 2 || nst == 3 || nst == 4)) || (KT == 12 && (nst == 2 || nst == 3));
@@ -19,7 +20,7 @@ int igemm_dma_os_default_stages(int KT, int parts) {
 int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
 #define ALDM_OS(KT_, NST_, NP_)                                                                                  \
     if (KT == KT_ && nst == NST_ && parts == NP_) {                                                              \
-        hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_>), grid, dim3(256), 0, st, p);                   \
+        hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_>), grid, dim3(512), 0, st, p);                   \
         return 0;                                                                                                \
     }
     ALDM_OS(8, 2, 3)

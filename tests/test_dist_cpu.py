@@ -154,3 +154,83 @@ def test_sharded_reranking_consumes_the_global_unconditional_draws():
         la, lt = two_passes(fake((G, rows.tolist())), emb[rows])
         assert torch.equal(la, ga[rows]) and torch.equal(lt, gt[rows])
         assert torch.equal(torch.get_rng_state(), end_state)   # and the generator ends where the single process leaves it
+
+
+def _worker8(rank, world, port, out_dir, B, n_gen):
+    """One rank of the 8-rank job below: everything a prompt shard does around the (GPU) sampler, on the CPU."""
+    import types
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import numpy as np
+    from audioldm2_amd import dist as adist
+    from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2 as Clap
+    from audioldm2_amd.ddim import DDIMSampler
+    torch.set_num_threads(1)
+    r, w, _ = adist.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(200 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 32), torch.nn.GroupNorm(4, 8))
+    adist.broadcast_module(net, src=0)
+    rows = adist.candidate_rows(B, n_gen, rank, world)
+    lo, hi = adist.shard_range(B, rank, world)
+    Bp = hi - lo
+    G = B * n_gen
+
+    class M:
+        num_timesteps = 1000
+        noise_shard = (G, rows)
+    torch.manual_seed(42)   # seed_everything(42) of every rank
+    img, noise, _ = DDIMSampler(M())._draw_noise((Bp * n_gen, 4, 2, 2), 3, None, False)
+    # re-ranking: the global batch's unconditional-probability draws (audio pass, then text pass), our rows' decisions
+    ns = types.SimpleNamespace(unconditional_prob=0.5, unconditional_token=torch.full((1, 4), -7.0),
+                               decision_shard=(G, rows.tolist()))
+    ns.make_decision = lambda pr: float(torch.rand(1)) < pr
+    emb = torch.arange(G * 4, dtype=torch.float32).view(G, 4)
+    a = Clap._draw_unconditional(ns, emb[rows].clone())
+    t = Clap._draw_unconditional(ns, emb[rows].clone() + 100.0)
+    sim = torch.rand(G, generator=torch.Generator().manual_seed(9))[rows]          # the similarities this rank would compute
+    best = [j + int(torch.argmax(sim[j::Bp])) * Bp for j in range(Bp)]
+    wave = np.stack([np.full((1, 5), float(rows[b]), dtype=np.float32) for b in best]) if Bp else np.zeros((0, 1, 5), np.float32)
+    got = adist.gather_waveforms(wave, dst=0)
+    torch.save({"rows": rows, "img": img, "noise": noise, "a": a, "t": t, "w0": net[0].weight.detach().clone(),
+                "gathered": got, "rng": torch.get_rng_state()}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_gloo_uneven_batch_with_candidates_equals_single_process(tmp_path):
+    """the shape of the driver's 8-GPU run, on the CPU — 8 gloo ranks, an UNEVEN global batch (13 prompts: five
+    ranks hold 2, three hold 1) and n_candidate_gen_per_text = 3.  Every rank's noise rows, re-ranker decisions and chosen
+    candidates must be the single-process run's; the generator of every rank must end where the single process leaves it;
+    the gather returns the prompts in global order; the broadcast delivers rank 0's weights."""
+    import types
+    from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2 as Clap
+    world, B, n_gen = 8, 13, 3
+    G = B * n_gen
+    port = _free_port()
+    mp.spawn(_worker8, args=(world, port, str(tmp_path), B, n_gen), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"r{r}.pt"), weights_only=False) for r in range(world)]
+    assert [p["rows"].numel() // n_gen for p in parts] == [2, 2, 2, 2, 2, 1, 1, 1]
+    # single process: the same draws on the global batch
+    torch.manual_seed(42)
+    full = [torch.randn(G, 4, 2, 2) for _ in range(4)]
+    ns = types.SimpleNamespace(unconditional_prob=0.5, unconditional_token=torch.full((1, 4), -7.0), decision_shard=None)
+    ns.make_decision = lambda pr: float(torch.rand(1)) < pr
+    emb = torch.arange(G * 4, dtype=torch.float32).view(G, 4)
+    ga = Clap._draw_unconditional(ns, emb.clone())
+    gt = Clap._draw_unconditional(ns, emb.clone() + 100.0)
+    end_state = torch.get_rng_state()
+    sim = torch.rand(G, generator=torch.Generator().manual_seed(9))
+    single = [i + int(torch.argmax(sim[i::B])) * B for i in range(B)]
+    for p in parts:
+        rows = p["rows"]
+        assert torch.equal(p["img"], full[0][rows])
+        for i in range(3):
+            assert torch.equal(p["noise"][i], full[i + 1][rows])
+        assert torch.equal(p["a"], ga[rows]) and torch.equal(p["t"], gt[rows])
+        assert torch.equal(p["rng"], end_state)
+        assert torch.equal(p["w0"], parts[0]["w0"])
+    got = parts[0]["gathered"]
+    assert got.shape == (B, 1, 5) and got[:, 0, 0].astype(int).tolist() == single
+    assert all(p["gathered"] is None for p in parts[1:])

@@ -341,6 +341,11 @@ def test_qkv_epilogue_and_presplit_attention_are_bitwise_the_fp32_kv_path(ops, B
 
 
 # ---- the operand-stationary form for short K (csrc/igemm_dma_os.h): aldm_igemm_force(32, 128, ..., 300 + ring depth) ------------
+# Same products in the same order per k-tile as igemm_dma_kernel, but accumulated by v_mfma_f32_16x16x32_bf16 (32 k per
+# instruction) instead of two chained 32x32x16 ones: equal to fp32 rounding, not bitwise.
+OS_TOL = 2e-6
+
+
 def _os_depths(ops, K):
     if ops.split_parts() == 3:
         return [2, 3] if K == 256 else [2]
@@ -348,8 +353,7 @@ def _os_depths(ops, K):
 
 
 def _os_vs_classic(ops, st, fn):
-    """fn() under the operand-stationary kernel and under igemm_dma_kernel (64x128 tile): the same products accumulated in the
-    same order through the same epilogue arithmetic -> BITWISE equal results."""
+    """fn() under the operand-stationary kernel and under igemm_dma_kernel (64x128 tile)."""
     ops.igemm_force(32, 128, 1, 0, 300 + st)
     try:
         y_os = fn()
@@ -363,9 +367,20 @@ def _os_vs_classic(ops, st, fn):
     return y_os, y_old
 
 
+def _img_tol(ops):
+    """Split images of two fp32 tensors that agree to OS_TOL: exact 3-part images agree as well; in a 2-part image a value on a
+    rounding boundary of `mid` may land on the other side (2^-17 relative)."""
+    return OS_TOL if exact_split(ops) else OS_TOL + 2.0 ** -16
+
+
+def _parts_to_float(img, part_dim):
+    """Raw int16 part images (k / v^T of ALDM_EPI_QKV) -> fp32 values (sum of the parts)."""
+    return (img.to(torch.int32) << 16).view(torch.float32).sum(dim=part_dim)
+
+
 @pytest.mark.parametrize("K,N,M", [(256, 256, 16384), (256, 768, 16384), (384, 384, 4096), (256, 128, 32 * 37 + 5),
                                    (256, 640, 100), (384, 1152, 4096 + 17)])
-def test_dma_os_linear_matches_classic_bitwise(ops, K, N, M):
+def test_dma_os_linear_matches_classic(ops, K, N, M):
     """Plain / bias / residual / alpha / both outputs: the UNet's K = C projections at the BASELINE batch (16384 x 256 -> 256 / 768,
     4096 x 384 -> 384), ragged M (rows past the end are fetched from the last row and discarded; the last block's chunk is
     short), N that is not a whole number of 128-column slabs, more and fewer blocks than compute units."""
@@ -380,18 +395,19 @@ def test_dma_os_linear_matches_classic_bitwise(ops, K, N, M):
     for st in _os_depths(ops, K):
         y_os, y_old = _os_vs_classic(ops, st, lambda: ops.linear(xs, pw0))
         assert rel_err(y_os, ref) < GEMM_TOL, st
-        assert torch.equal(y_os, y_old), st
+        assert rel_err(y_os, y_old) < OS_TOL, st
         (y_os, s_os), (y_old, s_old) = _os_vs_classic(ops, st, lambda: ops.linear(xs, pw, res=res, alpha=0.5, split_out="also"))
         assert rel_err(y_os, 0.5 * (ref + b.double() + res.double().cpu())) < GEMM_TOL, st
-        assert torch.equal(y_os, y_old) and torch.equal(s_os.data, s_old.data), st
+        assert rel_err(y_os, y_old) < OS_TOL and rel_err(s_os.float(), s_old.float()) < _img_tol(ops), st
+        assert_split_equals(ops, s_os, y_os, st)
         s_only, _ = _os_vs_classic(ops, st, lambda: ops.linear(xs, pw, res=res, alpha=0.5, split_out="only"))
-        assert torch.equal(s_only.data, s_os.data), st
+        assert torch.equal(s_only.data, s_os.data), st     # the same kernel twice: deterministic
 
 
 @pytest.mark.parametrize("C,M", [(256, 16384), (384, 4096), (256, 32 * 9 + 7)])
-def test_dma_os_geglu_matches_classic_bitwise(ops, C, M):
-    """The GEGLU epilogue: a value wave and its gate wave exchange their 32x32 tiles through the staging area and evaluate
-    value * gelu(gate) with the classic kernel's arithmetic (attention.py:37-45)."""
+def test_dma_os_geglu_matches_classic(ops, C, M):
+    """The GEGLU epilogue: a wave's 16 columns are 8 value columns and their 8 gate columns of the packed weight image; value *
+    gelu(gate) is evaluated in registers (one DPP row rotation) with the classic kernel's arithmetic (attention.py:37-45)."""
     x = torch.randn(1, M, C, generator=g(1))
     w1 = torch.randn(8 * C, C, generator=g(4)) / math.sqrt(C)
     b1 = torch.randn(8 * C, generator=g(5))
@@ -403,15 +419,17 @@ def test_dma_os_geglu_matches_classic_bitwise(ops, C, M):
     for st in _os_depths(ops, C):
         (y_os, s_os), (y_old, s_old) = _os_vs_classic(ops, st, lambda: ops.linear_geglu(xs, pw, split_out="also"))
         assert rel_err(y_os, ref) < GEMM_TOL, st
-        assert torch.equal(y_os, y_old) and torch.equal(s_os.data, s_old.data), st
+        assert rel_err(y_os, y_old) < OS_TOL and rel_err(s_os.float(), s_old.float()) < _img_tol(ops), st
+        assert_split_equals(ops, s_os, y_os, st)
         s_only, _ = _os_vs_classic(ops, st, lambda: ops.linear_geglu(xs, pw, split_out="only"))
         assert torch.equal(s_only.data, s_os.data), st
 
 
 @pytest.mark.parametrize("B,L,heads", [(16, 1024, 8), (4, 256, 12), (2, 96, 8)])
-def test_dma_os_qkv_epilogue_matches_classic_bitwise(ops, B, L, heads):
-    """ALDM_EPI_QKV from the operand-stationary kernel: q fp32, k as a split image, v transposed per key tile — the three
-    outputs of the classic kernel bit for bit (C = 256 / 384: whole 128-column slabs per segment)."""
+def test_dma_os_qkv_epilogue_matches_classic(ops, B, L, heads):
+    """ALDM_EPI_QKV from the operand-stationary kernel: q fp32, k as a split image, v transposed per key tile — the classic
+    kernel's three outputs to fp32 rounding (C = 256 / 384: whole 128-column slabs per segment), and the attention over them
+    within the GEMM tolerance of fp64."""
     C = heads * 32
     x = torch.randn(B, L, C, generator=g(1))
     wq, wk, wv = (torch.randn(C, C, generator=g(2 + i)) / math.sqrt(C) for i in range(3))
@@ -419,12 +437,19 @@ def test_dma_os_qkv_epilogue_matches_classic_bitwise(ops, B, L, heads):
     xs = ops.split_rows(x.cuda())
     for st in _os_depths(ops, C):
         (q1, k1, v1), (q0, k0, v0) = _os_vs_classic(ops, st, lambda: ops.linear_qkv(xs, pw, heads, L))
-        assert torch.equal(q1, q0) and torch.equal(k1, k0) and torch.equal(v1, v0), st
+        assert rel_err(q1, q0) < OS_TOL, st
+        assert rel_err(_parts_to_float(k1, 2), _parts_to_float(k0, 2)) < _img_tol(ops), st
+        assert rel_err(_parts_to_float(v1, 3), _parts_to_float(v0, 3)) < _img_tol(ops), st
+        a = ops.attention_presplit(q1, k1, v1, heads)
+        xd = xs.float().double().cpu()
+        sh = lambda t: t.view(B, L, heads, 32).transpose(1, 2)
+        ref = F.scaled_dot_product_attention(sh(xd @ wq.double().t()), sh(xd @ wk.double().t()), sh(xd @ wv.double().t()))
+        assert rel_err(a, ref.transpose(1, 2).reshape(B, L, C)) < GEMM_TOL, st
 
 
 def test_dma_os_refuses_what_it_cannot_run_and_hints_fall_back(ops):
-    """A FORCED operand-stationary launch outside its domain (3x3 conv; K = 128) fails loudly; the same request as a tuned HINT
-    (tables are keyed by geometry) falls back to aldm_igemm's own tile choice and still computes the right thing."""
+    """A FORCED operand-stationary launch outside its domain (K = 128: no instantiation) fails loudly; the same request as a tuned
+    HINT (tables are keyed by geometry) falls back to aldm_igemm's own tile choice and still computes the right thing."""
     x = torch.randn(1, 8, 8, 128, generator=g(1))
     w = torch.randn(128, 128, generator=g(2)) / math.sqrt(128)
     pw = ops.pack_conv(w, None)
@@ -442,10 +467,14 @@ def test_dma_os_refuses_what_it_cannot_run_and_hints_fall_back(ops):
         y0 = ops.linear(xs, pw)
     finally:
         ops.TUNE_LOG = None
+    had = tab.get(d_keys[0])
     tab[d_keys[0]] = [32, 128, 1, 302]
     try:
         y1 = ops.linear(xs, pw)
     finally:
-        del tab[d_keys[0]]
-    assert torch.equal(y0, y1)
+        if had is None:
+            del tab[d_keys[0]]
+        else:
+            tab[d_keys[0]] = had
+    assert rel_err(y0, y1) < OS_TOL
     assert rel_err(y1, xs.float().double().cpu() @ w.double().t()) < GEMM_TOL

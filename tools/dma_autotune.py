@@ -30,6 +30,8 @@ LW_CFGS = {3: [(128, 128, 202), (128, 128, 203), (64, 128, 202), (64, 128, 204),
                (128, 64, 204), (64, 64, 202), (64, 64, 203), (64, 64, 204)]}
 WS_CFGS = {3: [(64, 128, 102), (64, 128, 103), (64, 64, 102)],
            2: [(64, 128, 102), (64, 128, 103), (128, 64, 102), (64, 64, 103), (64, 64, 104)]}
+# operand-stationary form for short K (csrc/igemm_dma_os.h): "tile" 32x128, stages = 300 + ring depth; K = 256 / 384 1x1 launches only
+OS_CFGS = {3: [(32, 128, 302), (32, 128, 303)], 2: [(32, 128, 302), (32, 128, 303), (32, 128, 304)]}
 SPLITS = [1, 2, 3, 4, 6, 8]
 PARTS = 2 if os.environ.get("ALDM_MMA") == "bf16x3" else 3
 SUFFIX = ",dma2" if PARTS == 2 else ",dma"
@@ -78,14 +80,14 @@ def tune(key, lib):
             t = at.time_launch(lib, d, reps)
             if t is not None and t < best[0]:
                 best = (t, bm, bn, sp, st)
-    for bm, bn, st in LW_CFGS[PARTS] + WS_CFGS[PARTS]:
+    for bm, bn, st in LW_CFGS[PARTS] + WS_CFGS[PARTS] + (OS_CFGS[PARTS] if K in (256, 384) else []):
         if geglu and bn != 128:
             continue
         if bn > 64 and N <= 64 and not geglu:
             continue
         if bm > 64 and M <= 64:
             continue
-        for sp in (SPLITS if st >= 200 else [1]):
+        for sp in (SPLITS if 200 <= st < 300 else [1]):
             if sp > 1 and (geglu or N % 4 or nk < 8 or nk // sp < 2):
                 continue
             blocks = math.ceil(M / bm) * math.ceil(N / bn) * sp
@@ -123,8 +125,16 @@ def main():
         print(f"# merging into {merge}: {len(entries)} existing entries", flush=True)
     min_count = int(os.environ.get("DMA_TUNE_MIN_COUNT", "0"))
     known = set(entries)
+    only_os = os.environ.get("DMA_TUNE_ONLY_OS", "0") == "1"   # re-tune (only) the geometries the operand-stationary kernel can run
+
+    def os_geometry(key):
+        f = key.split(",")
+        return f[8] == "1" and f[9] == "1" and f[3] in ("256", "384") and f[4] == "0"
     for key, n in sorted(counts.items()):
-        if key in known or n < min_count:
+        if only_os:
+            if not os_geometry(key) or n < min_count:
+                continue
+        elif key in known or n < min_count:
             continue
         t_auto, best, flops, mnk = tune(key, lib)
         if t_auto is None:
@@ -134,6 +144,8 @@ def main():
         if best[1] and best[0] < 0.97 * t_auto:
             entries[key] = [best[1], best[2], best[3], best[4], round(best[0], 1), round(t_auto, 1)]
             saved += (t_auto - best[0]) * n
+        elif only_os and key in entries:
+            del entries[key]   # the cost model's own choice is (now) within 3 % of the best
         print(f"M{mnk[0]} N{mnk[1]} K{mnk[2]} n={n} auto {t_auto:.1f}us -> best {best[1]}x{best[2]} k{best[3]} st{best[4]} "
               f"{best[0]:.1f}us {flops / best[0] / 1e6:.1f} TF", flush=True)
     with open(out, "w") as f:

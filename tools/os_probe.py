@@ -1,5 +1,5 @@
 """Operand-stationary DMA GEMM (csrc/igemm_dma_os.h) vs the tuned igemm_dma_kernel choice on the UNet's K = C projections, same
-box, same process: bitwise equality against the classic kernel on the 64x128 tile, and time per launch, HIP-graph timed (R
+box, same process: agreement with the classic kernel on the 64x128 tile (fp32 rounding), and time per launch, HIP-graph timed (R
 launches per replay).  Usage (GPU box): python tools/os_probe.py [bf16x6|bf16x3] [--rows]"""
 import math
 import os
@@ -67,6 +67,17 @@ class Case:
                 ops.igemm_force(0, 0, 0)
 
 
+def close(a, b):
+    """fp32 outputs agree to 2e-6 max-norm; raw part images are compared after summing their parts (any layout: the part axis is
+    the one of size split_parts next to 32-wide rows — decode every int16 as a bf16 and compare the sums over ALL elements' blocks)."""
+    if a.dtype == torch.int16:
+        fa = (a.to(torch.int32) << 16).view(torch.float32).double()
+        fb = (b.to(torch.int32) << 16).view(torch.float32).double()
+        return float((fa.sum() - fb.sum()).abs()) <= 1e-3 * float(fb.abs().sum()) and \
+            float((fa - fb).abs().max()) <= 2.0 ** -7 * float(fb.abs().max())   # hi parts equal up to an ulp of bf16
+    return float((a.double() - b.double()).abs().max()) <= 2e-6 * float(b.double().abs().max())
+
+
 def flat(y):
     ys = y if isinstance(y, tuple) else (y,)
     return [t.data if isinstance(t, ops.SplitT) else t for t in ys]
@@ -93,9 +104,9 @@ def main():
         best = (t_auto, "auto")
         for st in depths:
             y_os = flat(c.run((32, 128, 300 + st)))
-            same = all(torch.equal(a, b) for a, b in zip(y_os, y_old))
+            same = all(close(a, b) for a, b in zip(y_os, y_old))
             t = graph_time(lambda: c.run((32, 128, 300 + st)))
-            line += f" os{st} {t:6.1f} ({c.flops / t / 1e6:5.0f} TF){'' if same else ' !=classic'}"
+            line += f" os{st} {t:6.1f} ({c.flops / t / 1e6:5.0f} TF){'' if same else ' !~classic'}"
             if t < best[0]:
                 best = (t, f"os{st}")
         if ROWS:
