@@ -108,12 +108,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-step-probe", action="store_true")
-    ap.add_argument("--cpu-ddim-steps", type=int, default=8)
+    ap.add_argument("--cpu-ddim-steps", type=int, default=6)
     ap.add_argument("--no-fast", "--no-strict", dest="no_fast", action="store_true",
                     help="skip the bf16x3 (16-bit operand significands) re-run reported under `fast`")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations reported under `configs`")
     ap.add_argument("--configs-steps", type=int, default=1, help="timed jobs per other configuration (after one warm-up job)")
-    ap.add_argument("--fast-steps", type=int, default=2, help="timed jobs of the fast re-run")
+    ap.add_argument("--fast-steps", type=int, default=1, help="timed jobs of the fast re-run (after one warm-up job)")
     ap.add_argument("--no-conditioners", action="store_true", help="skip the conditioner stacks reported under `conditioners`")
     ap.add_argument("--no-api-default", action="store_true", help="skip the n_candidate_gen_per_text = 3 job (`api_default`)")
     return ap.parse_args()
@@ -180,7 +180,7 @@ def conditioner_probe(model_name, B):
     cfgs = hip_cond_stage_config(model_name)
     models = {}
     for k, c in cfgs.items():
-        m = instantiate_from_config(c).cuda().eval()
+        m = instantiate_from_config(c).to("cuda").eval()   # (.to, not .cuda(): the reference's CLAP wrapper shadows .cuda with a bool)
         _set_stub_tokenizers(m)
         models[k] = (m, c["cond_stage_key"])
     batch = make_batch_for_text_to_audio(PROMPT, batchsize=B)
@@ -401,7 +401,7 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
     # the baseline is the best of a sweep, with the winning count reported as `cores`
     sweep = {}
     ncpu = os.cpu_count() or 8
-    for th in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+    for th in [t for t in (16, 32, 64) if t <= ncpu] or [ncpu]:
         torch.set_num_threads(th)
         ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, 1, 1.0, o.buffers["alphas_cumprod"])  # warm
         t0 = time.time()
@@ -578,7 +578,7 @@ def main():
             from audioldm2_amd.clap import CLAPAudioEmbeddingClassifierFreev2
             torch.manual_seed(11)
             clap = CLAPAudioEmbeddingClassifierFreev2(embed_mode="audio", unconditional_prob=0.0,
-                                                      sampling_rate=int(ld.sampling_rate)).cuda().eval()
+                                                      sampling_rate=int(ld.sampling_rate)).to("cuda").eval()
             clap.tokenize = _StubRobertaTokenizer()
             clap.weights_loaded = True   # random-init by construction here (no checkpoint offline): the ranking itself is meaningless
             ld.clap = clap
@@ -587,15 +587,16 @@ def main():
             def job3():
                 return ld.generate_batch(b3, unconditional_guidance_scale=3.5, ddim_steps=args.ddim_steps, n_gen=3, duration=10)
             seed_everything(42)
-            w3 = job3()
+            ld.generate_batch(b3, unconditional_guidance_scale=3.5, ddim_steps=2, n_gen=3, duration=10)   # warm: CLAP weight images
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            w3 = job3()
+            w3 = job3()   # includes the eager first step + graph capture of the 24-sample geometry (~0.3 s of ~14 s)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t0
             assert w3.shape[:2] == (B, 1) and np.isfinite(w3).all()
             out["api_default"] = {"value": round(B * audio_seconds / dt3, 3), "unit": "audio-s/s (delivered clips)", "steps": 1,
-                                  "warmup": 1, "ms_per_step": round(dt3 * 1e3, 2), "n_candidate_gen_per_text": 3,
+                                  "warmup": "one 2-step job (the timed job re-captures its step graph)", "ms_per_step": round(dt3 * 1e3, 2),
+                                  "n_candidate_gen_per_text": 3,
                                   "samples_generated": 3 * B, "mma": aops.MMA_MODE,
                                   "what": "generate_batch(n_gen=3): 3 x (sample_log + VAE decode + HiFi-GAN) + CLAP re-ranking "
                                           "(HTSAT-base + RoBERTa-base, random init, stub tokenizer); conditioning resident",
@@ -659,7 +660,12 @@ def main():
         out["conditioners"] = {}
         for name in ("audioldm2-full", "audioldm_48k", "audioldm2-full-large-1150k", "audioldm2-speech-gigaspeech"):
             try:
-                ent = conditioner_probe(name, B)
+                if name == "audioldm2-full-large-1150k" and "ms_per_batch" in out["conditioners"].get("audioldm2-full", {}):
+                    ent = dict(out["conditioners"]["audioldm2-full"])   # the same conditioner stack (utils.py:118-120: only the UNet differs)
+                    ent.pop("job_ms_without", None), ent.pop("value_including_conditioners", None), ent.pop("share_of_wall_clock", None)
+                    ent["what"] += " [measured once, on audioldm2-full: the stack is identical]"
+                else:
+                    ent = conditioner_probe(name, B)
                 job_ms = out["ms_per_step"] if name == "audioldm2-full" else out.get("configs", {}).get(name, {}).get("ms_per_step")
                 secs = audio_seconds if name == "audioldm2-full" else out.get("configs", {}).get(name, {}).get("audio_seconds_per_prompt")
                 if isinstance(job_ms, (int, float)) and secs:
