@@ -688,7 +688,9 @@ static int attention_launch(const float* q, const float* k, const float* v, floa
         const char* e = getenv("ALDM_ATTN_PIPE");
         return e == nullptr || e[0] != '0';
     }();
-    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 64 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
+    // (not for Lq < 128: with 64 queries per wave a 64-query launch keeps ONE wave of each block busy — 16 x 20 heads x 64 x 64 in
+    //  bf16x6: 13.0 us with 64 queries per wave, 8.0 us with 32, profiles/r04_attn_probe_fp32_pv.txt)
+    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 128 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
     const int gm = g_attn_mma.load();
     const int amode = gm < 0 ? default_attn_mode() : gm;
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
@@ -741,7 +743,9 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
         const char* e = getenv("ALDM_ATTN_QT");
         return e ? atoi(e) : 0;
     }();
-    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 64 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
+    // (not for Lq < 128: with 64 queries per wave a 64-query launch keeps ONE wave of each block busy — 16 x 20 heads x 64 x 64 in
+    //  bf16x6: 13.0 us with 64 queries per wave, 8.0 us with 32, profiles/r04_attn_probe_fp32_pv.txt)
+    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 128 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
     dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
     hipStream_t st = (hipStream_t)stream;
     const float* kf = reinterpret_cast<const float*>(k_split);
