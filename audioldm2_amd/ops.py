@@ -938,6 +938,49 @@ def softmax_rows_masked(x: torch.Tensor, keymask: torch.Tensor, q_pos0: int, sca
     return y
 
 
+# ---- single-position decode step of the GPT-2 sequence generator (aldm_decode_linear / aldm_decode_attention) ----------
+DECODE_MAX_ROWS = 16
+
+
+def decode_linear(x: torch.Tensor, w_kn: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+                  ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, act: int = ACT_NONE,
+                  res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(LayerNorm(x) @ w_kn + bias) + res for M <= 16 rows: x [M, K], w_kn [K, N] fp32 (transformers Conv1D's own
+    layout), ln = (gamma, beta, eps) or None.  Exact fp32 FMA, deterministic; a weight stream, not a tile GEMM."""
+    _chk(x, "decode_linear.x"); _chk(w_kn, "decode_linear.w")
+    M, K = x.shape
+    assert w_kn.dim() == 2 and w_kn.shape[0] == K and 1 <= M <= DECODE_MAX_ROWS
+    N = w_kn.shape[1]
+    if res is not None:
+        _chk(res, "decode_linear.res")
+        assert res.shape == (M, N)
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    _l.check(_l.load().aldm_decode_linear(x.data_ptr(), K, M, K, w_kn.data_ptr(), N, _p(bias), _p(g), _p(b), float(eps), act,
+                                          _p(res), N, y.data_ptr(), N, _stream()), "decode_linear")
+    return y
+
+
+def decode_attention(qkv: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                     keymask: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """The new position's attention over the key/value cache: qkv [B, 3 * heads * 64] (q | k | v rows of the new position),
+    pos: one-element int64 DEVICE tensor (its cache slot), caches [B * heads, n_tot, 64] (updated in place at slot pos),
+    keymask [B, n_tot] with slot pos already switched on.  Returns [B, heads * 64], heads merged."""
+    _chk(qkv, "decode_attention.qkv"); _chk(k_cache, "decode_attention.k_cache"); _chk(v_cache, "decode_attention.v_cache")
+    _chk(keymask, "decode_attention.keymask")
+    B = qkv.shape[0]
+    E = heads * 64
+    n_tot = keymask.shape[1]
+    assert qkv.shape == (B, 3 * E) and keymask.shape[0] == B
+    assert k_cache.shape == (B * heads, n_tot, 64) and v_cache.shape == k_cache.shape
+    assert pos.is_cuda and pos.dtype == torch.int64 and pos.numel() == 1
+    out = torch.empty((B, E), device=qkv.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_decode_attention(qkv.data_ptr(), 3 * E, pos.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                             keymask.data_ptr(), B, heads, n_tot, 0.125 if scale is None else float(scale),
+                                             out.data_ptr(), E, _stream()), "decode_attention")
+    return out
+
+
 def geglu(x: torch.Tensor) -> torch.Tensor:
     _chk(x, "geglu.x")
     C2 = x.shape[-1]

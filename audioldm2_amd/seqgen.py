@@ -14,7 +14,11 @@ and from the third generated token on the step is ONE HIP graph replay: the posi
 row, cache slot and key-mask entry are addressed through it, and a captured add advances it), so nothing in the launch
 sequence changes from token to token.  A decode step is ~160 launches of microsecond kernels (M = batch rows): launched from
 Python it costs 2.4 ms per token — 1.2 s for the speech model's 512 tokens, a third of that config's sampling job — replayed
-as a graph it is bound by the kernels (tools/cond_bench.py, profiles/r02_cond_bench.txt).
+as a graph it is bound by the kernels (tools/cond_bench.py, profiles/r02_cond_bench.txt): 1.8 ms per token at batch 8.
+Round 4: at batch <= 16 the decode step's GPT-2 blocks run on the single-position kernels of csrc/decode.hip
+(`aldm_decode_linear`: LayerNorm + Conv1D weight stream + bias / tanh-GELU / residual in one launch, exact fp32 FMA;
+`aldm_decode_attention`: cache append + scores + softmax + P.V per (sample, head)): 5 launches per block instead of ~17
+(`ALDM_SEQGEN_DECODE=general` selects the old path for A/B).
 All arithmetic goes through the C ABI: `aldm_layernorm`, `aldm_igemm` (projections with fused bias / tanh-GELU /
 residual; Q·K^T as the NT batched product, P·V through `aldm_pack_kn`), `aldm_softmax_rows_masked`, `aldm_axpby`;
 torch only moves data (concatenation, head split / merge copies, cache writes).
@@ -22,6 +26,7 @@ torch only moves data (concatenation, head split / merge copies, cache writes).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -116,11 +121,15 @@ class Sequence2AudioMAE(nn.Module):
         if self._pk is None:
             def conv1d(m):  # Conv1D [in, out] -> the Linear layout pack_conv expects
                 return ops.pack_conv(m.weight.detach().t().contiguous(), m.bias)
+            def kn(m):      # Conv1D's own [in, out] weight + bias: the operand of the single-position decode kernels
+                return (_f(m.weight), _f(m.bias))
             blocks = []
             for b in self.model.h:
                 blocks.append(dict(ln1=(_f(b.ln_1.weight), _f(b.ln_1.bias)), ln2=(_f(b.ln_2.weight), _f(b.ln_2.bias)),
                                    c_attn=conv1d(b.attn.c_attn), c_proj=conv1d(b.attn.c_proj),
-                                   c_fc=conv1d(b.mlp.c_fc), m_proj=conv1d(b.mlp.c_proj)))
+                                   c_fc=conv1d(b.mlp.c_fc), m_proj=conv1d(b.mlp.c_proj),
+                                   kn_attn=kn(b.attn.c_attn), kn_proj=kn(b.attn.c_proj), kn_fc=kn(b.mlp.c_fc),
+                                   kn_mproj=kn(b.mlp.c_proj)))
             self._pk = dict(blocks=blocks, ln_f=(_f(self.model.ln_f.weight), _f(self.model.ln_f.bias)),
                             inp=[ops.pack_conv(l.weight, l.bias) for l in self.input_sequence_embed_linear],
                             wpe=_f(self.model.wpe.weight), sos=_f(self.start_of_sequence_tokens.weight),
@@ -186,6 +195,15 @@ class Sequence2AudioMAE(nn.Module):
         Z, n_tot = B * N_HEAD, keymask.shape[1]
         wpe = pk["wpe"].index_select(0, pos).expand(B, 1, N_EMBD).contiguous()
         h = ops.axpby(tok.contiguous(), wpe, 1.0, 1.0).view(B, N_EMBD)
+        if B <= ops.DECODE_MAX_ROWS and os.environ.get("ALDM_SEQGEN_DECODE", "fast") != "general":
+            # B rows per Linear: weight streams, 5 launches per block (csrc/decode.hip) instead of the general path's ~17
+            for l, blk in enumerate(pk["blocks"]):
+                qkv = ops.decode_linear(h, *blk["kn_attn"], ln=(*blk["ln1"], LN_EPS))
+                o = ops.decode_attention(qkv, pos, kc[l], vc[l], keymask, N_HEAD)
+                h = ops.decode_linear(o, *blk["kn_proj"], res=h)
+                m = ops.decode_linear(h, *blk["kn_fc"], ln=(*blk["ln2"], LN_EPS), act=ACT_GELU_TANH)
+                h = ops.decode_linear(m, *blk["kn_mproj"], res=h)
+            return ops.layernorm(h, pk["ln_f"][0], pk["ln_f"][1], LN_EPS).view(B, 1, N_EMBD)
         for l, blk in enumerate(pk["blocks"]):
             a = ops.layernorm(h, blk["ln1"][0], blk["ln1"][1], LN_EPS)
             qkv = ops.linear(a, blk["c_attn"]).view(B, 1, 3, N_HEAD, HEAD_DIM)
@@ -243,7 +261,6 @@ class Sequence2AudioMAE(nn.Module):
             toks.index_copy_(1, e["slot"], new)
             e["pos"] += 1
             e["slot"] += 1
-        import os
         run = GraphStepper(step, use_graph=x.is_cuda and os.environ.get("ALDM_NO_GRAPH", "0") != "1")
         for _ in range(steps - 1):
             run()

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* ---- library / error ------------------------------------------------------------------ */
-int aldm_version(void);              /* ABI version, bumped on any struct change            */
+int aldm_version(void);              /* ABI version (7), bumped on any struct / entry change */
 const char* aldm_last_error(void);   /* message of the last failing call on this thread     */
 
 /* ---- activations usable as prologue (applied to the gathered input) or epilogue -------- */
@@ -325,6 +325,29 @@ int aldm_softmax_rows(const float* x, float* y, int64_t M, int N, float scale, v
  * batch b takes part iff keymask[b, j] != 0 and j <= q_pos0 + i for query row i; excluded keys get weight 0.       */
 int aldm_softmax_rows_masked(const float* x, float* y, int B, int heads, int q_rows, int N, float scale,
                              const float* keymask, int q_pos0, void* stream);
+
+/* ---- single-position decode step of the GPT-2 sequence generator (ABI v7) ----------------------------------------------
+ * audiomae_gen/sequence_input.py:294-325 calls transformers' GPT2Model once per generated AudioMAE token (512 dependent calls for
+ * the speech model, 8 for text-to-audio); with a key/value cache each call is ONE new position per sample: M = batch <= 16 rows
+ * through every Linear.  At that M the layers are weight streams, not matrix-core work, and the general path spends its time in
+ * launches (~17 per GPT-2 block).  These two entry points are the decode step's layer body in 5 launches per block.
+ *
+ * aldm_decode_linear: y[M, N] = act(LN(x)[M, K] . W[K, N] + bias) + res — transformers Conv1D (weight stored [in, out] = [K, N],
+ *   used as is, fp32) with the preceding LayerNorm (ln_gamma / ln_beta both NULL: none; statistics over the whole row, biased
+ *   variance, eps inside the root; K <= 1024 then) and the following activation (ALDM_ACT_NONE | GELU | GELU_TANH | SILU | TANH) /
+ *   residual add fused.  1 <= M <= 16; K a multiple of 64 * ceil(K / 1024).  Exact fp32 FMA in a fixed order (deterministic,
+ *   no workspace): one block per 32 output columns sums all of K.                                                            */
+int aldm_decode_linear(const float* x, int ldx, int M, int K, const float* w_kn, int N, const float* bias,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, int act, const float* res, int ldr,
+                       float* y, int ldy, void* stream);
+/* aldm_decode_attention: attention of the new position over the key/value cache (transformers GPT2Attention._attn with
+ *   layer_past, head dim 64): qkv [B, 3E] = the c_attn output rows (q | k | v, E = heads * 64) of the new position; *pos (a
+ *   DEVICE int64, so a captured graph advances it) = its cache slot.  Writes k / v into k_cache / v_cache
+ *   [B * heads, n_tot, 64] at slot *pos, scores q.k_j * scale against every key j <= *pos with keymask[b, j] != 0 (the caller
+ *   switches slot *pos on first; slots behind it are not part of the sequence yet), softmax, P.V; out [B, E] head-merged.
+ *   n_tot <= 1024 (GPT-2's n_positions).                                                                                     */
+int aldm_decode_attention(const float* qkv, int ldq, const int64_t* pos, float* k_cache, float* v_cache, const float* keymask,
+                          int B, int heads, int n_tot, float scale, float* out, int ldo, void* stream);
 
 /* ---- elementwise ---------------------------------------------------------------------- */
 /* GEGLU gate: y[m, c] = x[m, c] * gelu_erf(x[m, C + c]), x: [M, 2C] (attention.py:42-44)   */

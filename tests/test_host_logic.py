@@ -237,7 +237,30 @@ def _torch_ops_stand_in():
         ok = (keymask[:, None, None, :] != 0) & (j <= (q_pos0 + torch.arange(T))[:, None])[None, None]
         return torch.where(ok, x * scale, torch.full([], float("-inf"))).softmax(-1)
 
+    def _act(y, act):
+        if act == ACT_GELU_TANH:
+            return 0.5 * y * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (y + 0.044715 * y ** 3)))
+        assert act == 0
+        return y
+
+    def decode_linear(x, w_kn, bias=None, *, ln=None, act=0, res=None):
+        if ln is not None:
+            x = F.layer_norm(x, (x.shape[-1],), ln[0], ln[1], ln[2])
+        y = _act(x @ w_kn + (0 if bias is None else bias), act)
+        return y if res is None else y + res
+
+    def decode_attention(qkv, pos, kc, vc, keymask, heads):
+        B, E = qkv.shape[0], heads * 64
+        n_tot = keymask.shape[1]
+        q, k, v = (qkv[:, i * E:(i + 1) * E].reshape(B, heads, 1, 64) for i in range(3))
+        kc.view(B, heads, n_tot, 64).index_copy_(2, pos, k)
+        vc.view(B, heads, n_tot, 64).index_copy_(2, pos, v)
+        s = (q.reshape(B * heads, 1, 64) @ kc.transpose(1, 2)) * 0.125
+        s = torch.where(keymask[:, None, None, :] != 0, s.view(B, heads, 1, n_tot), torch.full([], float("-inf")))
+        return (s.softmax(-1).view(B * heads, 1, n_tot) @ vc).view(B, E)
+
     return types.SimpleNamespace(
+        DECODE_MAX_ROWS=16, decode_linear=decode_linear, decode_attention=decode_attention,
         pack_conv=lambda w, b=None: PW(w, b), linear=linear,
         layernorm=lambda x, g, b, eps=1e-5: F.layer_norm(x, (x.shape[-1],), g, b, eps),
         axpby=lambda a, b, alpha, beta=0.0: alpha * a + beta * b,

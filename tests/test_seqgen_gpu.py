@@ -53,12 +53,82 @@ def test_linear_with_tanh_gelu_epilogue_and_residual():
         assert rel(y, ref) < 5e-5
 
 
+def _gelu_new(y):
+    return 0.5 * y * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (y + 0.044715 * y ** 3)))
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 8, 16])
+@pytest.mark.parametrize("K,N,use_ln,act,use_res", [(768, 2304, True, "none", False), (768, 768, False, "none", True),
+                                                    (768, 3072, True, "gelu_new", False), (3072, 768, False, "none", True),
+                                                    (64, 100, True, "gelu_new", True), (2048, 40, False, "none", False)])
+def test_decode_linear_matches_fp64(M, K, N, use_ln, act, use_res):
+    """aldm_decode_linear (LayerNorm + Conv1D weight stream + bias + tanh-GELU + residual in one launch, M <= 16 rows) against
+    fp64, bit-identical when repeated (fixed summation order, no cross-block reduction)."""
+    from audioldm2_amd import ops
+    g = torch.Generator().manual_seed(1000 * M + K + N)
+    x = torch.randn(M, K, generator=g) * 2 + 0.3
+    w = torch.randn(K, N, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ga, be = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    xd = x.double()
+    if use_ln:
+        xd = F.layer_norm(xd, (K,), ga.double(), be.double(), 1e-5)
+    ref = xd @ w.double() + b.double()
+    if act == "gelu_new":
+        ref = _gelu_new(ref)
+    if use_res:
+        ref = ref + r.double()
+    kw = dict(ln=(ga.cuda(), be.cuda(), 1e-5) if use_ln else None, act=ops.ACT_GELU_TANH if act == "gelu_new" else ops.ACT_NONE,
+              res=r.cuda() if use_res else None)
+    ys = [ops.decode_linear(x.cuda(), w.cuda(), b.cuda(), **kw) for _ in range(3)]
+    assert rel(ys[0], ref) < 2e-6
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+
+
+def test_decode_linear_refuses_what_it_cannot_run():
+    from audioldm2_amd import ops
+    x, w = torch.zeros(17, 64).cuda(), torch.zeros(64, 64).cuda()
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.decode_linear(x, w)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.decode_linear(torch.zeros(2, 48).cuda(), torch.zeros(48, 64).cuda())
+
+
+@pytest.mark.parametrize("B,heads,n_tot,pos", [(3, 12, 40, 17), (8, 12, 600, 599), (2, 4, 1024, 0), (1, 12, 36, 35)])
+def test_decode_attention_matches_torch(B, heads, n_tot, pos):
+    """aldm_decode_attention: cache append at the device-side slot, masked scores, softmax, P.V, heads merged — against
+    torch fp64 on the same caches; only slot `pos` of the caches changes."""
+    from audioldm2_amd import ops
+    g = torch.Generator().manual_seed(7 + n_tot)
+    E = heads * 64
+    qkv = torch.randn(B, 3 * E, generator=g)
+    kc = torch.randn(B * heads, n_tot, 64, generator=g)
+    vc = torch.randn(B * heads, n_tot, 64, generator=g)
+    km = (torch.rand(B, n_tot, generator=g) > 0.3).float()
+    km[:, pos + 1:] = 0
+    km[:, pos] = 1
+    kc2, vc2 = kc.clone(), vc.clone()
+    q, k, v = (qkv[:, i * E:(i + 1) * E].reshape(B * heads, 64) for i in range(3))
+    kc2[:, pos], vc2[:, pos] = k, v
+    s = torch.einsum("zd,znd->zn", q.double(), kc2.double()) * 0.125
+    s = torch.where(km.repeat_interleave(heads, 0) != 0, s, torch.full([], float("-inf"), dtype=torch.float64))
+    ref = torch.einsum("zn,znd->zd", s.softmax(-1), vc2.double()).reshape(B, E)
+    kd, vd = kc.cuda(), vc.cuda()
+    out = ops.decode_attention(qkv.cuda(), torch.tensor([pos], device="cuda"), kd, vd, km.cuda(), heads)
+    assert rel(out, ref) < 2e-6
+    assert torch.equal(kd.cpu(), kc2) and torch.equal(vd.cpu(), vc2)
+
+
+@pytest.mark.parametrize("decode", ["fast", "general"])
 @pytest.mark.parametrize("fixture,cfg,T", [("seqgen_full_8step_b2", cases.SEQGEN_FULL, 20),
                                            ("seqgen_speech_24step_b2", cases.SEQGEN_SPEECH, 40)])
-def test_sequence_generator_matches_reference_generate(fixture, cfg, T):
+def test_sequence_generator_matches_reference_generate(fixture, cfg, T, decode, monkeypatch):
     """The HIP generator (key/value-cached decode) against the REAL Sequence2AudioMAE.generate fixture: full model's
-    configuration (8 tokens from CLAP + T5) and the speech model's (CLAP + phonemes; 24 of its 512 steps)."""
+    configuration (8 tokens from CLAP + T5) and the speech model's (CLAP + phonemes; 24 of its 512 steps, graph-replayed
+    decode steps on the single-position kernels of csrc/decode.hip, and on the general tile-GEMM path)."""
     from audioldm2_amd.seqgen import Sequence2AudioMAE
+    monkeypatch.setenv("ALDM_SEQGEN_DECODE", decode)
     m = Sequence2AudioMAE(base_learning_rate=2e-4, sequence_gen_length=cfg["steps"], sequence_input_key=cfg["keys"],
                           sequence_input_embed_dim=cfg["dims"], cond_stage_config={}, batchsize=16)
     with open(os.path.join(GOLD, fixture + "_keys.json")) as f:
