@@ -269,9 +269,10 @@ def _torch_ops_stand_in():
         gemm_packed_batched=lambda a, bp, K, N: a @ bp)
 
 
+@pytest.mark.parametrize("decode", ["fast", "general"])
 @pytest.mark.parametrize("fixture,cfg_name,T", [("seqgen_full_8step_b2", "SEQGEN_FULL", 20),
                                                 ("seqgen_speech_24step_b2", "SEQGEN_SPEECH", 40)])
-def test_sequence_generator_host_logic_matches_reference_fixture(monkeypatch, fixture, cfg_name, T):
+def test_sequence_generator_host_logic_matches_reference_fixture(monkeypatch, fixture, cfg_name, T, decode):
     """audioldm2_amd.seqgen.Sequence2AudioMAE: the reference's state-dict keys load strictly, and its key/value-cached
     decode (fixed-length cache, masked future positions) reproduces the REAL reference's generate() fixture when the
     device ops are replaced by torch stand-ins — i.e. the orchestration is right; the kernels are tests/test_seqgen_gpu.py's
@@ -280,6 +281,7 @@ def test_sequence_generator_host_logic_matches_reference_fixture(monkeypatch, fi
     from oracle import cases, weights
     cfg = getattr(cases, cfg_name)
     monkeypatch.setattr(seqgen, "ops", _torch_ops_stand_in())
+    monkeypatch.setenv("ALDM_SEQGEN_DECODE", decode)   # the decode step (>= 16 tokens) on the single-position ops / the general ones
     m = seqgen.Sequence2AudioMAE(base_learning_rate=2e-4, sequence_gen_length=cfg["steps"], sequence_input_key=cfg["keys"],
                                  sequence_input_embed_dim=cfg["dims"], cond_stage_config={}, batchsize=16)
     with open(os.path.join(GOLD, fixture + "_keys.json")) as f:
