@@ -237,17 +237,9 @@ class Sequence2AudioMAE(nn.Module):
         keymask[:, :P] = mask
         out = self._forward_positions(x, 0, kc, vc, keymask)
         tok = out[:, -1:, :].contiguous()
-        if steps < self.GRAPH_MIN_STEPS:
-            toks = []
-            for t in range(steps):
-                toks.append(tok)
-                if t + 1 == steps:
-                    break
-                keymask[:, P + t] = 1.0  # the token joins the sequence (its own key is visible to it)
-                tok = self._forward_positions(tok, P + t, kc, vc, keymask)
-            return torch.cat(toks, dim=1), cond_dict
-        # long generation (the speech model: 512 tokens): the decode step reads / advances device-side state only and is
-        # replayed as one HIP graph (eager the first time, captured the second: ddim.GraphStepper)
+        # every later token: one decode step that reads / advances device-side state only.  Long generations (the speech
+        # model: 512 tokens) replay it as one HIP graph (eager the first time, captured the second: ddim.GraphStepper);
+        # the 8-token text-to-audio configurations run the same step eagerly — a capture is not worth 7 steps
         from .ddim import GraphStepper
         toks = torch.empty((B, steps, N_EMBD), device=dev)
         toks[:, 0:1] = tok
@@ -261,7 +253,8 @@ class Sequence2AudioMAE(nn.Module):
             toks.index_copy_(1, e["slot"], new)
             e["pos"] += 1
             e["slot"] += 1
-        run = GraphStepper(step, use_graph=x.is_cuda and os.environ.get("ALDM_NO_GRAPH", "0") != "1")
+        run = GraphStepper(step, use_graph=x.is_cuda and steps >= self.GRAPH_MIN_STEPS and
+                           os.environ.get("ALDM_NO_GRAPH", "0") != "1")
         for _ in range(steps - 1):
             run()
         run.fn = None          # break the closure cycle: the graph and its pool go with this call, not with a later collection
