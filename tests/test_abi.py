@@ -61,6 +61,27 @@ def test_argument_validation_reports_errors_without_gpu():
     assert l.aldm_groupnorm_stats(None, None, 1, 1, 8, 0, 32, 1e-5, None, None, None, None, None, None) != 0
 
 
+def test_decode_entry_points_validate_before_launch():
+    """aldm_decode_linear / aldm_decode_attention (ABI v7) refuse what their kernels cannot run — more than 16 rows, a K the
+    passes do not tile, a fused LayerNorm over rows longer than the registers hold, a cache longer than GPT-2's 1024
+    positions — before any launch, so it is observable without a GPU."""
+    from audioldm2_amd import lib
+    l = lib.load()
+    p = ctypes.c_void_p(4096)   # never dereferenced: validation fails first
+
+    def lin(M, K, N, ln=False):
+        g = p if ln else None
+        return l.aldm_decode_linear(p, K, M, K, p, N, None, g, g, 1e-5, 0, None, 0, p, N, None)
+    for M, K, N, ln, msg in ((17, 768, 768, False, "rows"), (0, 768, 768, False, "rows"), (8, 48, 64, False, "multiple of 64"),
+                             (8, 1024 + 64, 64, False, "multiple of 128"), (8, 2048, 64, True, "LayerNorm")):
+        assert lin(M, K, N, ln) != 0
+        assert msg in l.aldm_last_error().decode()
+    assert l.aldm_decode_attention(p, 3 * 768, p, p, p, p, 8, 12, 1025, 0.125, p, 768, None) != 0
+    assert "1024" in l.aldm_last_error().decode()
+    assert l.aldm_decode_attention(p, 768, p, p, p, p, 8, 12, 64, 0.125, p, 768, None) != 0
+    assert "pitch" in l.aldm_last_error().decode()
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from audioldm2_amd import lib
     monkeypatch.setattr(lib, "_lib", None)
