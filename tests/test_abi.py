@@ -82,6 +82,39 @@ def test_decode_entry_points_validate_before_launch():
     assert "pitch" in l.aldm_last_error().decode()
 
 
+def test_every_tuned_dma_table_entry_plans_onto_the_hinted_kernel():
+    """The shipped tuning tables of the DMA-fed kernel family (audioldm2_amd/tuning/mi355x_igemm_dma*.json): every entry's
+    (tile, split-K, kernel form + ring depth) hint is ACCEPTED by the host-side planner for the geometry it is keyed on — a
+    stale entry (a form that cannot run that shape any more) would silently fall back to the cost model and lose its tuning."""
+    import json
+    from audioldm2_amd import lib, ops
+    l = lib.load()
+    n = 0
+    for name, parts in (("mi355x_igemm_dma.json", 3), ("mi355x_igemm_dma_bf16x3.json", 2)):
+        with open(os.path.join(ROOT, "audioldm2_amd", "tuning", name)) as f:
+            entries = json.load(f)["entries"]
+        assert len(entries) > 100
+        for key, v in entries.items():
+            fields = key.split(",")
+            d = lib.IgemmDesc()
+            for k, x in zip(ops._TUNE_FIELDS, fields):
+                setattr(d, k, int(x))
+            d.K = (d.C1 + d.C2) * d.KH * d.KW
+            d.a_split, d.split_parts, d.w, d.w_split = 4096, parts, 4096, 8192   # never dereferenced by the planner
+            d.out, d.alpha = 1 << 20, 1.0
+            d.ldo = d.N // 2 if d.epi_mode == lib.EPI_GEGLU else d.N
+            d.ws, d.ws_floats = 16, 1 << 40
+            d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = v[:4]
+            bm, bn, sp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            assert l.aldm_igemm_plan(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn), None, ctypes.byref(sp), None,
+                                     None) == 0, (key, l.aldm_last_error())
+            assert (bm.value, bn.value, sp.value) == tuple(v[:3]), (name, key, v)
+            stages = l.aldm_igemm_plan_stages(ctypes.byref(d))
+            assert stages == v[3] or (v[3] % 100 == 0 and stages // 100 == v[3] // 100), (name, key, v, stages)
+            n += 1
+    assert n >= 300
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from audioldm2_amd import lib
     monkeypatch.setattr(lib, "_lib", None)
