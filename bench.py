@@ -567,6 +567,10 @@ def main():
                 except Exception as e:  # pragma: no cover
                     st["probe_error"] = str(e)
                 out["fast"] = st
+        except Exception as e:  # pragma: no cover - the headline above must still be printed
+            if world > 1:
+                raise
+            out["fast"] = {"error": repr(e)}
         finally:
             aops.set_mma(prev)
             unet.drop_step_caches()
@@ -677,7 +681,10 @@ def main():
                 out["conditioners"][name] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(1, args.cpu_ddim_steps, args.ddim_steps)
+            try:
+                out["cpu_baseline"] = cpu_baseline(1, args.cpu_ddim_steps, args.ddim_steps)
+            except Exception as e:  # pragma: no cover - never lose the measured line to the baseline leg
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
