@@ -7,8 +7,10 @@ for `audioldm2-full`, batch 8 prompts per GPU, 10.24 s of 16 kHz audio per promp
 configs[1]); n_candidate_gen_per_text = 1; conditioning resident in HBM (synthetic), conditioners timed separately.
 metric = audio-seconds / second (whole job, all GPUs).  Weak scaling: per-GPU batch fixed.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 and no WORLD_SIZE in the environment: bench.py re-launches itself
+                                                        under torch.distributed.run, one rank per GPU, 127.0.0.1 rendezvous)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (the same thing)
+  python bench.py --gpus 2 --dry-launch                 (no GPU needed: spawns the ranks on gloo and prints what each one sees)
 
 The headline runs in the library's DEFAULT product mode, "bf16x6": fp32 storage / accumulation, every product evaluated as 6 bf16
 MFMA partial products of exact 3-part operand splits — fp32-grade (2.4e-7 rms per contraction; the fp32 MFMA itself: 2.1e-7), i.e.
@@ -116,7 +118,69 @@ def parse():
     ap.add_argument("--fast-steps", type=int, default=1, help="timed jobs of the fast re-run (after one warm-up job)")
     ap.add_argument("--no-conditioners", action="store_true", help="skip the conditioner stacks reported under `conditioners`")
     ap.add_argument("--no-api-default", action="store_true", help="skip the n_candidate_gen_per_text = 3 job (`api_default`)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check without a GPU: spawn --gpus ranks (gloo), rendezvous, shard the global batch, print ONE "
+                         "JSON line listing every rank; no kernels run")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (default: a free one)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: re-execute this script as N ranks of ONE
+    node (one process per GPU, RCCL; gloo for --dry-launch), rendezvous on 127.0.0.1 — exactly the command the docstring
+    gives, so the contract line comes from the same code path either way.  Preflight: the node must expose N GPUs
+    (torch.cuda.device_count(), unless --dry-launch or ALDM_DIST_BACKEND=gloo lets ranks share one).  Returns the exit code."""
+    import subprocess
+    n = args.gpus
+    if not args.dry_launch and os.environ.get("ALDM_DIST_BACKEND") != "gloo":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s) (torch.cuda.device_count()); "
+                  f"nothing was launched", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / cross-process tensors need it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(4, (os.cpu_count() or 8) // n)))
+    port = args.master_port or _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: WORLD_SIZE unset and --gpus {n}: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args):
+    """One rank of `--dry-launch`: what the real run does before its first kernel — init_distributed (gloo here), the rank's
+    contiguous slice of the global batch, a bucketed weight broadcast of a small module, barrier, gather — and rank 0 prints
+    ONE JSON line listing every rank.  Needs no GPU; tests/test_host_logic.py runs it with two ranks."""
+    from audioldm2_amd import dist as adist
+    rank, world, local = adist.init_distributed(backend="gloo")
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    gB = args.batch * world
+    lo, hi = adist.shard_range(gB, rank, world)
+    torch.manual_seed(1234 + rank)
+    probe = torch.nn.Linear(32, 32)
+    sent = adist.broadcast_module(probe, src=0)
+    mine = {"rank": rank, "local_rank": local, "pid": os.getpid(), "prompts": [lo, hi], "backend": torch.distributed.get_backend(),
+            "weight_checksum": float(probe.weight.detach().double().sum())}
+    every = [None] * world
+    torch.distributed.all_gather_object(every, mine)
+    torch.distributed.barrier()
+    if rank == 0:
+        assert len({e["weight_checksum"] for e in every}) == 1, "the weight broadcast did not reach every rank"
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "global_batch": gB, "ranks": every,
+                          "weight_broadcast_bytes": sent,
+                          "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "environment"}),
+              flush=True)
+    torch.distributed.destroy_process_group()
 
 
 def fast_wanted(args, aops):
@@ -430,13 +494,17 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_launch:
+        return dry_launch(args)
     from audioldm2_amd import dist as adist
     from audioldm2_amd import ops as aops
     if args.mma:
         aops.set_mma(args.mma)
     from audioldm2_amd.pipeline import build_model, make_batch_for_text_to_audio, seed_everything
     rank, world, local = adist.init_distributed()
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus} (run `python bench.py --gpus N`: it launches the ranks itself)"
     if world > 1:  # one process per GPU on one host: do not oversubscribe the cores with intra-op threads
         torch.set_num_threads(max(4, (os.cpu_count() or 8) // world))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
@@ -518,6 +586,8 @@ def main():
                        "weight_broadcast_bytes": bcast_bytes},
         }
         if per_rank is not None:
+            out["config"]["dist_backend"] = torch.distributed.get_backend()   # "nccl" == RCCL on ROCm
+            out["config"]["dist_world_size"] = torch.distributed.get_world_size()
             out["per_rank_seconds"] = per_rank
             out["rank_skew_pct"] = round(100.0 * (max(per_rank) - min(per_rank)) / max(per_rank), 2)
         try:

@@ -210,6 +210,32 @@ def test_bench_contract_defaults_and_no_cpu_path():
         assert r.returncode != 0 and "needs the MI355X" in r.stderr and not r.stdout.strip()
 
 
+@pytest.mark.timeout(600)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) re-launches itself under torch.distributed.run with
+    a 127.0.0.1 rendezvous.  --dry-launch runs the launcher and the pre-kernel distributed set-up on gloo:
+    two ranks, contiguous prompt slices of the global batch, the weight broadcast reaching both; without --dry-launch the
+    preflight refuses a node that has fewer GPUs than ranks instead of dying in an assert inside a rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout   # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["dry_launch"] and rec["n_gpus"] == 2 and rec["global_batch"] == 16 and rec["launched_by"] == "torch.distributed.run"
+    assert [e["rank"] for e in rec["ranks"]] == [0, 1] and [e["prompts"] for e in rec["ranks"]] == [[0, 8], [8, 16]]
+    assert len({e["pid"] for e in rec["ranks"]}) == 2 and rec["weight_broadcast_bytes"] == (32 * 32 + 32) * 4
+    assert len({e["weight_checksum"] for e in rec["ranks"]}) == 1
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 2 and "exposes 0 GPU(s)" in r.stderr and not r.stdout.strip()
+
+
 def _torch_ops_stand_in():
     """Torch (CPU) stand-ins for the handful of ops audioldm2_amd/seqgen.py calls — TEST ONLY: lets the host logic of the
     sequence generator (cache bookkeeping, masks, positions, head split / merge) run on a CPU-only box against the
