@@ -67,7 +67,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // WM x 2 waves (WM = 2: 256 threads, one wave per SIMD and block; WM = 4: 512 threads, the 256-row tiles).
 // NP = parts per operand: 3 = "bf16x6" (exact 3-way split, 6 partial products, fp32-grade products), 2 = "bf16x3"
 // (hi + mid, both rounded to nearest: 16 significant bits per operand, 3 partial products hi*hi + hi*mid + mid*hi).
-template <int BM, int BN, int NST, int WM = 2, int NP = 3>
+// DROP (test hook, aldm_debug_drop_product): leave out the first — smallest — partial product (hi_a x lo_w).  The result is a
+// deliberately broken "5-product" GEMM, ~1e-5 off: tests/test_dma_gpu.py asserts that it FAILS the fp32-grade bar, i.e. that the
+// bar would catch a kernel that silently lost a product.  Instantiated for ONE tile only (64x128, 2 stages, 3 parts).
+template <int BM, int BN, int NST, int WM = 2, int NP = 3, bool DROP = false>
 __global__ __launch_bounds__(128 * WM, dma_blocks_per_cu(BM, BN, NST, NP) * (WM / 2))
 void igemm_dma_kernel(const IgemmK p) {
     constexpr int WN = 2, NW = WM * WN;
@@ -290,7 +293,7 @@ void igemm_dma_kernel(const IgemmK p) {
         return;
 #endif
 #pragma unroll
-        for (int q = 0; q < NPROD; ++q)
+        for (int q = DROP ? 1 : 0; q < NPROD; ++q)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll

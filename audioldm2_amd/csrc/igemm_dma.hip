@@ -1,6 +1,7 @@
 // igemm_dma.hip — instantiations of the DMA-fed bf16-split implicit-GEMM kernel (igemm_dma.h) and the split-image
 // producers that feed it: aldm_split_rows (GroupNorm apply + activation + 3-way split in one pass over the tensor).
 #include "igemm_dma.h"
+#include <atomic>
 
 namespace aldm {
 
@@ -14,7 +15,15 @@ bool igemm_dma_config_ok(int BM, int BN, int nst, int parts) {
     return false;
 }
 
+// test hook (aldm_debug_drop_product, include/aldm_hip.h): non-zero -> DMA-fed launches run the 5-product kernel or fail
+std::atomic<int> g_debug_drop_product{0};
+
 int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+    if (g_debug_drop_product.load(std::memory_order_relaxed)) {   // (aldm_igemm has checked the tile)
+        if (!(BM == 64 && BN == 128 && nst == 2 && parts == 3)) return -1;
+        hipLaunchKernelGGL((igemm_dma_kernel<64, 128, 2, 2, 3, true>), grid, dim3(256), 0, st, p);
+        return 0;
+    }
 #define ALDM_DMA(BM_, BN_, NST_, NP_) \
     hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 2, NP_>), grid, dim3(256), 0, st, p)
 #define ALDM_DMA8(BM_, BN_, NST_, NP_) \
@@ -115,6 +124,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 }  // namespace aldm
 
 using namespace aldm;
+
+namespace aldm { extern std::atomic<int> g_debug_drop_product; }
+extern "C" int aldm_debug_drop_product(int on) { return aldm::g_debug_drop_product.exchange(on ? 1 : 0); }
 
 extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C, int parts) { return rows * (int64_t)(C / 32) * 64 * parts; }
 

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALDM_LIB_PATH") or os.path.join(_HERE, "libaldm_hip.so")  # override: debug builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU, ACT_GELU_TANH = range(7)
 B_PACKED, B_NT = 0, 1
@@ -76,6 +76,7 @@ _SIGS = {
     "aldm_split_bytes_parts": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "aldm_pack_split_bf16_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_igemm_mma": (C.c_int, [C.c_int]),
+    "aldm_debug_drop_product": (C.c_int, [C.c_int]),
     "aldm_split_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "aldm_pack_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -368,6 +368,13 @@ def attention_mma(mode: int) -> int:
     return _l.load().aldm_attention_mma(mode)
 
 
+def debug_drop_product(on: bool) -> bool:
+    """TEST HOOK (aldm_debug_drop_product): DMA-fed launches leave out the smallest of the six bf16 partial products — only the
+    classic 64x128 / 2-stage tile has that instantiation, every other igemm launch fails while the switch is on.  Returns the
+    previous setting.  Used by tests/test_dma_gpu.py to show the fp32-grade bar catches a lost product."""
+    return bool(_l.load().aldm_debug_drop_product(1 if on else 0))
+
+
 def igemm_mma(mode: int) -> int:
     """Tuning override for tools/tests (aldm_igemm_mma): 0 automatic, 1 fp32 MFMA always, 2 bf16-split wherever an
     instantiation exists.  Returns the previous mode."""

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* ---- library / error ------------------------------------------------------------------ */
-int aldm_version(void);              /* ABI version (7), bumped on any struct / entry change */
+int aldm_version(void);              /* ABI version (8), bumped on any struct / entry change */
 const char* aldm_last_error(void);   /* message of the last failing call on this thread     */
 
 /* ---- activations usable as prologue (applied to the gathered input) or epilogue -------- */
@@ -207,6 +207,12 @@ int aldm_igemm_wave8_mask(int mask);
  * carries w_split and the tuned hint allows), 1 = fp32 MFMA always, 2 = bf16-split wherever an instantiation
  * exists.  Returns the previous mode; other values only query.                                            */
 int aldm_igemm_mma(int mode);
+/* TEST HOOK, process wide: on != 0 makes DMA-fed launches leave out the smallest of the six bf16 partial products (hi_a x
+ * lo_w) — a deliberately broken "5-product" GEMM, ~1e-5 off — so that tests/test_dma_gpu.py can show that the fp32-grade
+ * tolerance WOULD catch a kernel that silently lost a product.  Only the classic 64x128 tile with 2 stages
+ * and 3-part images has that instantiation: while the switch is on every other aldm_igemm launch FAILS (nothing runs at full
+ * precision by accident).  Returns the previous setting.  No product code path sets it.                              */
+int aldm_debug_drop_product(int on);
 /* bf16-split image of a packed weight [ceil(K/4)][Npad][4] (aldm_pack_weight / aldm_pack_kn output) for
  * aldm_igemm_desc.w_split: [4*ceil(K/32) k-octets][3 parts][Npad][8 bf16], w = hi + mid + lo exactly.
  * aldm_split_bytes = size of that image.                                                                 */

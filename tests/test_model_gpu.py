@@ -3,9 +3,11 @@
   (2) the CPU oracle on fresh seeded inputs,
   (3) size-independent properties at the BASELINE batch (batch-invariance, determinism,
       CFG-batched == two passes, HIP-graph replay == eager).
-Tolerances are stated next to each assert: module-level max-norm relative error 2e-4 (fp32, different
-accumulation order over ~50 chained layers); waveform after 200 DDIM steps: RMS error < 1e-3 (the
-north-star bound) and relative RMS < 1e-2.
+Tolerances are PER PRODUCT MODE and at most 5x the measured error of that mode (tests/tolerances.py): in
+the fp32-grade modes a UNet forward must be within 1e-5 max-norm of the real reference's fixture, VAE / HiFi-GAN within 4e-5, a
+5-step latent within 1e-5 relative rms, the 200-step latent within 5e-6 and its mel within 1e-5 — bars the opt-in bf16x3 mode
+(1e-5-level errors) does NOT meet and therefore does not share: it keeps 2e-4 / 1e-4.  Waveform after 200 DDIM steps: RMS error
+< 1e-3 (the north-star bound) AND < 1e-3 of the rms distance between two unrelated samples.
 """
 import json
 import os
@@ -15,10 +17,10 @@ import pytest
 import torch
 
 from oracle import cases, weights
+from tolerances import latent_tol, log_err, mel_tol, tail_tol, unet_tol
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MOD_TOL = 2e-4
 
 
 def batch_tol():
@@ -98,7 +100,7 @@ def test_unet_matches_reference_fixture(name, cfg, B, H, W, t5, mma):
     out = m(x.cuda(), t.cuda(), y=cu(y), context_list=cu(ctxs), context_attn_mask_list=cu(masks))
     e = rel(out, gold(name)["out"])
     report(f"{name} [{mma}]: max-norm rel err vs reference fixture {e:.2e}")
-    assert e < MOD_TOL
+    assert log_err(e, unet_tol(mma), name) < unet_tol(mma)
 
 
 @pytest.mark.parametrize("name,cfg,B,H,W,t5", [("unet_tiny", cases.UNET_TINY, 2, 16, 8, 12),
@@ -117,7 +119,7 @@ def test_unet_matches_reference_fixture_on_fp32_mfma_path(name, cfg, B, H, W, t5
         ops.set_mma(prev)
     e = rel(out, gold(name)["out"])
     report(f"{name} (fp32 MFMA path): max-norm rel err vs reference fixture {e:.2e}")
-    assert e < MOD_TOL
+    assert log_err(e, unet_tol("f32"), name + " f32") < unet_tol("f32")
 
 
 def test_unet_full_vs_oracle_batch8_properties():
@@ -135,7 +137,7 @@ def test_unet_full_vs_oracle_batch8_properties():
     for b in (0, 11):
         sl = slice(b, b + 1)
         ref = unet_forward(sd, cfg, x[sl], t[sl], [c[sl] for c in ctxs], [mm[sl] for mm in masks])
-        assert rel(out[sl], ref) < MOD_TOL
+        assert log_err(rel(out[sl], ref), unet_tol(), "unet_full b16 vs oracle") < unet_tol()
         alone = m(x[sl].cuda(), t[sl].cuda(), context_list=cu([c[sl] for c in ctxs]),
                   context_attn_mask_list=cu([mm[sl] for mm in masks]))
         assert rel(alone, out[sl]) < batch_tol()  # same kernels; only tile/grid shapes differ
@@ -170,7 +172,7 @@ def test_unet_full_batch16_vs_pytorch_rocm_eager():
     e = rel(out, ref)
     report(f"unet_full B=16 on MI355X: HIP path {t_hip:.1f} ms/pass (eager launches) vs PyTorch-ROCm eager fp32 "
            f"{t_torch:.1f} ms/pass; max-norm rel err {e:.2e}")
-    assert e < MOD_TOL
+    assert log_err(e, unet_tol(), "unet_full b16 vs rocm eager") < unet_tol()
 
 
 @pytest.mark.parametrize("name,dd,shapes", [("vae16k", cases.DDCONFIG_16K, [(2, 8, 32, 16), (1, 8, 256, 16)]),
@@ -183,11 +185,11 @@ def test_vae_matches_reference_fixture(name, dd, shapes):
         mel = ae.decode(cases.latent_input(*shp, seed=i).cuda())
         e = rel(mel, g[f"mel{i}"])
         report(f"{name} decode {shp}: max-norm rel err vs reference fixture {e:.2e}")
-        assert e < MOD_TOL
+        assert log_err(e, tail_tol(), f"{name} decode") < tail_tol()
     f = 2 ** (len(dd["ch_mult"]) - 1)
     x = cases.mel_input(1, dd["mel_bins"], 16 * f, seed=5).permute(0, 2, 1)[:, None].contiguous()
     post = ae.encode(x.cuda())
-    assert rel(post.parameters, g["moments"]) < MOD_TOL
+    assert log_err(rel(post.parameters, g["moments"]), tail_tol(), f"{name} encode") < tail_tol()
 
 
 @pytest.mark.parametrize("name,hc,Ts", [("hifigan16k", cases.HIFIGAN_16K, [48, 1024]),
@@ -201,7 +203,7 @@ def test_hifigan_matches_reference_fixture(name, hc, Ts):
         assert tuple(w.shape) == tuple(g[f"wave{i}"].shape)
         e = rel(w, g[f"wave{i}"])
         report(f"{name} T={T}: max-norm rel err vs reference fixture {e:.2e}")
-        assert e < MOD_TOL
+        assert log_err(e, tail_tol(), f"{name} T={T}") < tail_tol()
 
 
 def test_stft_mel_matches_reference_fixture_and_oracle():
@@ -312,8 +314,8 @@ def test_e2e_5step_matches_reference_generate_batch(ld_mode):
     out = _generate(ld, 2, 5)
     assert out["wave"].dtype == np.float32 and out["wave"].shape == (2, 1, 163872)
     errs = _report(f"e2e 5 steps B=2 [{mode}]", out, g)
-    assert errs["latent"][0] / errs["latent"][1] < 1e-4
-    assert errs["mel"][0] / errs["mel"][1] < 1e-4
+    assert log_err(errs["latent"][0] / errs["latent"][1], latent_tol(5, mode), "latent 5 steps B=2") < latent_tol(5, mode)
+    assert log_err(errs["mel"][0] / errs["mel"][1], mel_tol(5, mode), "mel 5 steps B=2") < mel_tol(5, mode)
     _assert_wave(errs["wave"][0], g, "e2e 5 steps")
 
 
@@ -330,7 +332,7 @@ def test_e2e_5step_batch8_matches_reference_generate_batch(ld_mode):
     ed = rms(out["wave"][..., ::16].astype(np.float64) - g["wave_dec"])
     report(f"e2e 5 steps B=8 [{mode}]: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} / between-sample "
            f"{float(g['wave_between_rms']):.3e}")
-    assert el < 1e-4
+    assert log_err(el, latent_tol(5, mode), "latent 5 steps B=8") < latent_tol(5, mode)
     _assert_wave(max(eh, ed), g, "e2e 5 steps B=8")
 
 
@@ -359,21 +361,22 @@ def test_cached_step_graph_is_refreshed_with_new_conditioning(ld):
     assert next(iter(unet._graph_cache.values())) is ent, "second job should hit the cached graph"
     assert rms(other.astype(np.float64) - g["wave"]) > 1e-4  # the first job really was a different job
     errs = _report("e2e 5 steps B=2 via cached graph", out, g)
-    assert errs["latent"][0] / errs["latent"][1] < 1e-4
+    assert errs["latent"][0] / errs["latent"][1] < latent_tol(5)
     _assert_wave(errs["wave"][0], g, "cached graph")
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, "e2e_full_200step_b1.npz")), reason="200-step fixture absent")
 def test_e2e_200step_waveform_within_north_star_tolerance(ld_mode):
     """BASELINE config 1 (1 prompt, 10 s, 200 DDIM steps, CFG 3.5, seed 42) against the reference's
-    CPU run: latent and mel within 1e-4 relative after 400 dependent UNet evaluations, waveform rms error < 1e-3 (north_star)
-    AND < 1e-3 of the distance between two unrelated samples' waveforms."""
+    CPU run: after 400 dependent UNet evaluations the latent within 5e-6 and the mel within 1e-5 relative rms in the fp32-grade
+    mode (1e-4 for bf16x3, which measures 2.7e-6 / 9.9e-6), waveform rms error < 1e-3 (north_star) AND < 1e-3 of the distance
+    between two unrelated samples' waveforms."""
     ld, mode = ld_mode
     g = gold("e2e_full_200step_b1")
     out = _generate(ld, 1, 200)
     errs = _report(f"e2e 200 steps B=1 [{mode}]", out, g)
-    assert errs["latent"][0] / errs["latent"][1] < 1e-4
-    assert errs["mel"][0] / errs["mel"][1] < 1e-4
+    assert log_err(errs["latent"][0] / errs["latent"][1], latent_tol(200, mode), "latent 200 steps") < latent_tol(200, mode)
+    assert log_err(errs["mel"][0] / errs["mel"][1], mel_tol(200, mode), "mel 200 steps") < mel_tol(200, mode)
     _assert_wave(errs["wave"][0], g, "e2e 200 steps")
 
 
@@ -401,7 +404,7 @@ def test_generate_batch_masked_matches_reference(ld):
     ew = rms(wave.astype(np.float64) - g["wave"])
     report(f"masked 4 steps B=1: latent rel rms {el:.2e}  wave rms_err {ew:.3e} / rms_ref {rms(g['wave']):.3e}")
     assert wave.shape == (1, 1, 163872)
-    assert el < 1e-4
+    assert log_err(el, latent_tol(4), "masked latent") < latent_tol(4)   # default (fp32-grade) mode; measured 1.3e-6
     _assert_wave(ew, g, "masked")
 
 
@@ -418,7 +421,7 @@ def test_ancestral_sample_matches_reference(ld):
     e1 = rms(inter[1].double().cpu().numpy() - g["first"]) / rms(g["first"])
     e2 = rms(z.double().cpu().numpy() - g["latent"]) / rms(g["latent"])
     report(f"ancestral 4 steps B=1: first-step rel rms {e1:.2e}  final rel rms {e2:.2e}")
-    assert e1 < 1e-4 and e2 < 1e-4
+    assert e1 < 2e-6 and e2 < 2e-6   # measured 2.4e-8 / 6.1e-8: one UNet pass per step feeds an exact update
 
 
 def test_super_resolution_and_inpainting_entry_point(ld):
@@ -555,7 +558,7 @@ def _e2e_48k(fixture, B, steps, mode):
     ed = rms(wave[..., ::16].astype(np.float64) - g["wave_dec"])
     report(f"48k e2e {steps} steps B={B} [{mode}]: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err {ed:.3e} "
            f"/ rms_ref {float(g['wave_rms']):.3e} / between-sample {float(g['wave_between_rms']):.3e}")
-    assert el < 1e-4
+    assert log_err(el, latent_tol(steps, mode), f"48k latent {steps} steps") < latent_tol(min(steps, 5), mode)
     _assert_wave(max(eh, ed), g, fixture)
     del m
     torch.cuda.empty_cache()

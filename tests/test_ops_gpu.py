@@ -1,24 +1,25 @@
-"""Per-op parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 on the CPU.
+"""Per-op parity of the HIP kernels (through the C ABI) against PyTorch on the CPU evaluated in fp64 on the same fp32 inputs.
 
-Tolerances (stated per test): contractions accumulate in fp32 in a different order than ATen, so
-the bound is max|err| / max|ref| <= 5e-5; pure elementwise ops <= 2e-6.
+Tolerances (tests/tolerances.py, per product mode, <= 5x the measured error): a contraction in an fp32-grade mode (fp32 MFMA,
+bf16x6) max|err| / max|ref| <= 2e-6, behind a fused GroupNorm / activation prologue or in front of a GELU / softmax <= 5e-6;
+bf16x3 (16-bit operand significands) <= 5e-5; pure elementwise ops <= 2e-6.
 """
 import math
 
 import pytest
 import torch
-import torch.nn.functional as F
+from tolerances import F64 as F   # references in fp64 (every floating argument promoted)
+from tolerances import fused_tol, gemm_tol, log_err, stress_tol
 
 pytestmark = pytest.mark.gpu
 
-GEMM_TOL = 5e-5
 EW_TOL = 2e-6
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    return log_err(float((a - b).abs().max() / (b.abs().max() + 1e-30)), 0.0)
 
 
 def cl(x):  # NCHW -> NHWC on GPU
@@ -61,7 +62,7 @@ def test_conv2d(ops, B, C, N, H, W, k, s, p):
     ref = F.conv2d(x, w, b, stride=s, padding=p)
     pw = ops.pack_conv(w, b)
     y = ops.conv(cl(x), pw, stride=(s, s), pad=(p, p))
-    assert rel_err(uncl(y), ref) < GEMM_TOL
+    assert rel_err(uncl(y), ref) < gemm_tol()
 
 
 def test_conv_fused_prologue_epilogue(ops):
@@ -90,7 +91,7 @@ def test_conv_fused_prologue_epilogue(ops):
     assert rel_err(sc, sc_ref) < 1e-5
     y = ops.conv(a, pw, x2=b2, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU,
                  rowbias=emb.cuda(), res=cl(res))
-    assert rel_err(uncl(y), ref) < GEMM_TOL
+    assert rel_err(uncl(y), ref) < fused_tol()
 
 
 @pytest.mark.parametrize("bm,bn", [(128, 128), (128, 64), (64, 128), (64, 64), (128, 32)])
@@ -112,7 +113,7 @@ def test_igemm_every_tile_and_splitk(ops, bm, bn, splits):
         y2 = ops.conv(cl(x), pw, pad=(1, 1), rowbias=emb.cuda()[:, N:], act=ops.ACT_SILU, res=cl(res))
     finally:
         ops.igemm_force(0, 0, 0)
-    assert rel_err(uncl(y1), ref) < GEMM_TOL
+    assert rel_err(uncl(y1), ref) < fused_tol()
     assert torch.equal(y1, y2), "split-K reduce must be bitwise reproducible"
 
 
@@ -142,7 +143,7 @@ def test_igemm_two_wave_groups(ops, splits, with_pre):
         y2 = ops.conv(a, pw, pad=(1, 1), res=cl(res), **kw)
     finally:
         ops.igemm_force(0, 0, 0, 0)
-    assert rel_err(uncl(y1), ref) < GEMM_TOL
+    assert rel_err(uncl(y1), ref) < fused_tol()
     assert torch.equal(y1, y2)
 
 
@@ -158,7 +159,7 @@ def test_igemm_auto_splitk_deep_level(ops):
     sc, sh = ops.gn_stats(a, gamma.cuda(), beta.cuda(), groups=32, eps=1e-5)
     pw = ops.pack_conv(w)
     y = ops.conv(a, pw, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU)
-    assert rel_err(uncl(y), ref) < GEMM_TOL
+    assert rel_err(uncl(y), ref) < fused_tol()
     ops.igemm_force(64, 64, 1)
     try:
         y1 = ops.conv(a, pw, pad=(1, 1), pre=(sc, sh), pre_act=ops.ACT_SILU)
@@ -196,7 +197,7 @@ def test_igemm_eight_wave_tiles(ops, bm, bn, uniform, splits):
     finally:
         ops.igemm_wave8(-1)
         ops.igemm_force(0, 0, 0)
-    assert rel_err(uncl(y8), ref) < GEMM_TOL
+    assert rel_err(uncl(y8), ref) < fused_tol()
     assert torch.equal(y8, y4) and torch.equal(y8n, y4n)
 
 
@@ -224,7 +225,7 @@ def test_igemm_prologue_modes(ops, mode):
         kw = dict(pre=(sc.cuda(), sh.cuda()), pre_act=ops.ACT_GELU)
     ref = F.conv2d(h, w, None, padding=(0, 9), dilation=(1, 3))
     y = ops.conv(cl(x), ops.pack_conv(w), pad=(0, 9), dil=(1, 3), **kw)
-    assert rel_err(uncl(y), ref) < GEMM_TOL
+    assert rel_err(uncl(y), ref) < fused_tol()
 
 
 @pytest.mark.parametrize("M,C,inner", [(1024, 256, 1024), (300, 384, 1536), (64, 640, 2560), (70, 64, 32)])
@@ -237,7 +238,7 @@ def test_linear_geglu_fused(ops, M, C, inner):
     ref = val * F.gelu(gate)
     y = ops.linear_geglu(x.cuda(), ops.pack_geglu(w, b))
     assert y.shape == (M, inner)
-    assert rel_err(y, ref) < GEMM_TOL
+    assert rel_err(y, ref) < fused_tol()
 
 
 @pytest.mark.parametrize("bm,bn", [(128, 128), (64, 128)])
@@ -255,7 +256,7 @@ def test_linear_geglu_forced_tiles(ops, bm, bn):
         y = ops.linear_geglu(x.cuda(), pw)
     finally:
         ops.igemm_force(0, 0, 0)
-    assert rel_err(y, ref) < GEMM_TOL
+    assert rel_err(y, ref) < fused_tol()
 
 
 def test_weight_split_image_is_bit_exact_vs_numpy_restatement(ops):
@@ -308,7 +309,7 @@ def test_conv_upsample_nearest(ops):
     b = torch.randn(C, generator=g(3))
     ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
     y = ops.conv(cl(x), ops.pack_conv(w, b), pad=(1, 1), up=(2, 2))
-    assert rel_err(uncl(y), ref) < GEMM_TOL
+    assert rel_err(uncl(y), ref) < gemm_tol()
 
 
 def test_conv_asymmetric_pad_downsample(ops):
@@ -318,7 +319,7 @@ def test_conv_asymmetric_pad_downsample(ops):
     w = torch.randn(C, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
     ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2)
     y = ops.conv(cl(x), ops.pack_conv(w), stride=(2, 2), pad=(0, 0), out_hw=(H // 2, W // 2))
-    assert rel_err(uncl(y), ref) < GEMM_TOL
+    assert rel_err(uncl(y), ref) < gemm_tol()
 
 
 @pytest.mark.parametrize("M,K,N", [(77, 1024, 640), (4096, 256, 2048), (16, 512, 128), (300, 32, 32),
@@ -329,7 +330,7 @@ def test_linear(ops, M, K, N):
     b = torch.randn(N, generator=g(3))
     ref = F.linear(x, w, b)
     y = ops.linear(x.cuda(), ops.pack_conv(w, b))
-    assert rel_err(y, ref) < GEMM_TOL
+    assert rel_err(y, ref) < gemm_tol()
 
 
 @pytest.mark.parametrize("C,L,k,d", [(64, 999, 3, 1), (32, 2000, 7, 5), (128, 500, 11, 3)])
@@ -347,14 +348,14 @@ def test_conv1d_dilated_resblock_step(ops, C, L, k, d):
     xl = x.permute(0, 2, 1).contiguous().cuda().view(B, 1, L, C)
     pw = ops.pack_conv(w, b)
     y = ops.conv(xl, pw, pad=(0, pad), dil=(1, d), pre_act=ops.ACT_LRELU, pre_slope=0.1, res=xl)
-    assert rel_err(y.view(B, L, C).cpu().permute(0, 2, 1), r) < GEMM_TOL
+    assert rel_err(y.view(B, L, C).cpu().permute(0, 2, 1), r) < gemm_tol()
     # accumulate form: out = out + alpha*(conv + bias) + ... checked separately: alpha scales
     # the activation result, residual is added unscaled (see aldm_hip.h epilogue)
     acc = xs0.permute(0, 2, 1).contiguous().cuda().view(B, 1, L, C).clone()
     ops.conv(xl, pw, pad=(0, pad), dil=(1, d), pre_act=ops.ACT_LRELU, pre_slope=0.1, alpha=1.0 / 3,
              out=acc, accumulate=True)
     ref2 = xs0 + (r - x) / 3
-    assert rel_err(acc.view(B, L, C).cpu().permute(0, 2, 1), ref2) < GEMM_TOL
+    assert rel_err(acc.view(B, L, C).cpu().permute(0, 2, 1), ref2) < gemm_tol()
 
 
 @pytest.mark.parametrize("Cin,Cout,k,s,L", [(64, 32, 16, 5, 100), (32, 64, 16, 4, 77), (32, 32, 8, 2, 50),
@@ -378,7 +379,7 @@ def test_conv_transpose1d_polyphase(ops, Cin, Cout, k, s, L):
                  out=out, remap=(s, ph - p, Lout))
     got = out.view(B, Lout, Cout).cpu().permute(0, 2, 1)
     assert not torch.isnan(got).any(), "polyphase left holes"
-    assert rel_err(got, ref) < GEMM_TOL
+    assert rel_err(got, ref) < gemm_tol()
 
 
 def test_batched_gemm_nt_and_packed(ops):
@@ -386,16 +387,16 @@ def test_batched_gemm_nt_and_packed(ops):
     Z, M, K, N = 2, 300, 64, 200
     a = torch.randn(Z, M, K, generator=g(1))
     bm = torch.randn(Z, N, K, generator=g(2))
-    ref = torch.bmm(a, bm.transpose(1, 2)) * 0.125
+    ref = torch.bmm(a.double(), bm.double().transpose(1, 2)) * 0.125
     y = ops.gemm_nt(a.cuda(), bm.cuda(), alpha=0.125)
-    assert rel_err(y, ref) < GEMM_TOL
+    assert rel_err(y, ref) < gemm_tol()
     # P V: [Z, M, Kk] @ [Z, Kk, D]
     Kk, D = 200, 64
     pmat = torch.rand(Z, M, Kk, generator=g(3))
     vmat = torch.randn(Z, Kk, D, generator=g(4))
-    ref2 = torch.bmm(pmat, vmat)
+    ref2 = torch.bmm(pmat.double(), vmat.double())
     y2 = ops.gemm_packed_batched(pmat.cuda(), ops.pack_kn(vmat.cuda()), Kk, D)
-    assert rel_err(y2, ref2) < GEMM_TOL
+    assert rel_err(y2, ref2) < gemm_tol()
 
 
 def test_frames_gemm_stft(ops):
@@ -410,12 +411,12 @@ def test_frames_gemm_stft(ops):
     frames = ref.shape[-1]
     pw = ops.pack_conv(basis[:, 0, :])  # [N=2F, K=n_fft] linear layout
     y = ops.frames_gemm(sig, frames, hop, pw)
-    assert rel_err(y.cpu().permute(0, 2, 1), ref) < GEMM_TOL
+    assert rel_err(y.cpu().permute(0, 2, 1), ref) < gemm_tol()
     Fq = n_fft // 2 + 1
     mag, ph = ops.mag_phase(y, Fq, 132)
     re, im = ref[:, :Fq], ref[:, Fq:]
     mref = torch.sqrt(re ** 2 + im ** 2).permute(0, 2, 1).reshape(-1, Fq)
-    assert rel_err(mag[:, :Fq], mref) < GEMM_TOL
+    assert rel_err(mag[:, :Fq], mref) < gemm_tol()
     assert float(mag[:, Fq:].abs().max()) == 0.0
 
 
@@ -478,6 +479,9 @@ def test_layernorm(ops, M, C):
     assert rel_err(y, ref) < 5e-6
 
 
+ATTN_MODE_NAME = {1: "f32", 2: "bf16x6", 3: "bf16x3"}   # aldm_attention_mma codes
+
+
 def ref_attention(q, k, v, heads, mask=None):
     """attention.py:343-367 restated (einsum / masked_fill(-finfo.max) / softmax / einsum)."""
     B, Lq, Cc = q.shape
@@ -518,7 +522,7 @@ def test_attention_d32(ops, B, heads, Lq, Lk, masked):
         mask[0, :] = 0  # sample 0: every key masked -> reference degenerates to uniform weights
         if B > 1:
             mask[1, 0] = 1
-    ref = ref_attention(q.contiguous(), k.contiguous(), v.contiguous(), heads, mask)
+    ref = ref_attention(q.double().contiguous(), k.double().contiguous(), v.double().contiguous(), heads, mask)   # fp64
     qd, kvd = qb.cuda(), kvb.cuda()
     for mode in (1, 2, 3):  # fp32 MFMA, bf16x6, bf16x3
         prev = ops.attention_mma(mode)
@@ -527,7 +531,7 @@ def test_attention_d32(ops, B, heads, Lq, Lk, masked):
                               mask=None if mask is None else mask.cuda())
         finally:
             ops.attention_mma(prev)
-        assert rel_err(y, ref) < (5e-5 if mode == 3 else GEMM_TOL), f"attention mma mode {mode}"
+        assert rel_err(y, ref) < fused_tol(ATTN_MODE_NAME[mode]), f"attention mma mode {mode}"
 
 
 @pytest.mark.parametrize("Lk,masked", [(8, True), (8, False), (40, True), (33, False), (32, True), (64, False), (1, False),
@@ -550,8 +554,8 @@ def test_attention_loads_no_key_past_the_last(ops, Lk, masked):
         mask[:, Lk // 2:] = 0
         mask[:, 0] = 1
         mask = mask.cuda()
-    ref = ref_attention(qd.cpu(), kvd[:, :, :Cc].cpu().contiguous(), kvd[:, :, Cc:].cpu().contiguous(), heads,
-                        None if mask is None else mask.cpu())
+    ref = ref_attention(qd.cpu().double(), kvd[:, :, :Cc].cpu().double().contiguous(), kvd[:, :, Cc:].cpu().double().contiguous(),
+                        heads, None if mask is None else mask.cpu())
     for mode in (1, 2, 3):
         prev = ops.attention_mma(mode)
         try:
@@ -559,7 +563,7 @@ def test_attention_loads_no_key_past_the_last(ops, Lk, masked):
         finally:
             ops.attention_mma(prev)
         assert torch.isfinite(y).all(), f"mode {mode}: a key past Lk entered the product"
-        assert rel_err(y, ref) < (5e-5 if mode == 3 else GEMM_TOL), f"mode {mode}"
+        assert rel_err(y, ref) < fused_tol(ATTN_MODE_NAME[mode]), f"mode {mode}"
 
 
 def test_attention_online_softmax_rescale(ops):
@@ -570,9 +574,9 @@ def test_attention_online_softmax_rescale(ops):
     v = torch.randn(B, L, 32, generator=g(3))
     k[0, 200] = q[0, 5] * 20.0   # spike: query 5 against key 200 (7th tile)
     k[0, 3] = q[0, 100] * 15.0   # and an early spike for another row
-    ref = ref_attention(q, k, v, heads)
+    ref = ref_attention(q.double(), k.double(), v.double(), heads)
     y = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads)
-    assert rel_err(y, ref) < GEMM_TOL
+    assert rel_err(y, ref) < fused_tol()   # the attention kernel follows the library's product mode (bf16x6 by default)
 
 
 def test_softmax_rows_geglu_embedding(ops):
@@ -668,10 +672,10 @@ print("ERR", float((o - ref).abs().max() / ref.abs().max()))
 
 
 # ---- bf16x3 under trained-like statistics (VERDICT r2 "weak" #2, next #3d) ----------------------------------------------------
-# The default product mode keeps 16 significant bits per operand.  Every other test feeds it U(+-1/sqrt(fan_in)) weights and
-# O(1) activations; a trained checkpoint has heavy-tailed weights, channels with |mean| >> std in front of the skip convs and
-# attention logits tens of units apart.  The per-op bar (max-norm relative error <= 5e-5 against fp64 of the SAME fp32 inputs)
-# must hold there too, or bf16x3 has no business being the default.
+# Every other test feeds the kernels U(+-1/sqrt(fan_in)) weights and O(1) activations; a trained checkpoint has heavy-tailed weights,
+# channels with |mean| >> std in front of the skip convs and attention logits tens of units apart.  The per-mode stress bars
+# (max-norm relative error against fp64 of the SAME fp32 inputs: 5e-6 for the fp32-grade default, 5e-5 for the opt-in bf16x3 mode
+# with its 16 significant bits per operand) must hold there too.
 def report(line):
     """stdout + gpurun_out/parity_report.txt (merged back by gpurun)"""
     import os
@@ -709,7 +713,7 @@ def test_split_gemm_heavy_tailed_weights_and_large_mean_activations(mode):
         ref = x.double() @ w.double().t() + b.double()
         err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
         report(f"stress GEMM heavy-tailed W, mean/std 1e3 channels ({mode}): max-norm rel err {err:.2e}")
-        assert err < 5e-5, err
+        assert log_err(err, stress_tol(mode), "stress gemm") < stress_tol(mode), err   # per-mode: 5e-6 (measured 1.1e-6) / 5e-5 (5.6e-6)
     finally:
         o.set_mma(prev)
 
@@ -733,6 +737,6 @@ def test_attention_sharp_logits(mode):
         ref = (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(B, L, H * 32)
         err = float((out - ref).abs().max() / ref.abs().max())
         report(f"stress attention |logit| up to {float(s.abs().max()):.0f} ({mode}): max-norm rel err {err:.2e}")
-        assert err < 5e-5, err
+        assert log_err(err, stress_tol(mode), "stress attention") < stress_tol(mode), err   # 5e-6 (measured 7.0e-7) / 5e-5 (1.4e-5)
     finally:
         o.set_mma(prev)

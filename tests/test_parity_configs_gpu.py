@@ -11,6 +11,8 @@ import torch
 
 from oracle import cases, weights
 
+from tolerances import fused_tol, latent_tol, log_err
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -89,14 +91,14 @@ def _e2e_named(model_name, fixture, keys_json, B, steps, mode):
     between = float(g["wave_between_rms"])
     report(f"{model_name} e2e {steps} steps B={B} [{mode}]: latent rel rms {el:.2e}  wave(head) rms_err {eh:.3e}  wave(1/16) rms_err "
            f"{ed:.3e} / rms_ref {float(g['wave_rms']):.3e} / between-sample {between:.3e}")
-    assert el < 1e-4
+    assert log_err(el, latent_tol(5, mode), f"{model_name} latent {steps} steps B={B}") < latent_tol(5, mode)   # per-mode bar, <= 5x measured
     assert between > 1e-2 and max(eh, ed) < 1e-3 and max(eh, ed) < 1e-3 * between
     del m
     torch.cuda.empty_cache()
 
 
 def _ref_attention(q, k, v, heads, mask=None):
-    """attention.py:343-367 restated (einsum / masked_fill(-finfo.max) / softmax / einsum), fp32 on the CPU."""
+    """attention.py:343-367 restated (einsum / masked_fill(-finfo.max) / softmax / einsum) in the dtype of its arguments."""
     B, Lq, Cc = q.shape
     d = Cc // heads
 
@@ -122,7 +124,7 @@ def _attention_case(Lk, masked, mode):
     if masked:
         mask = (torch.rand(B, Lk, generator=gen) > 0.25).float()
         mask[:, 0] = 1
-    ref = _ref_attention(q, kv[:, :, :Cc].contiguous(), kv[:, :, Cc:].contiguous(), heads, mask)
+    ref = _ref_attention(q.double(), kv[:, :, :Cc].double().contiguous(), kv[:, :, Cc:].double().contiguous(), heads, mask)   # fp64
     kvd = kv.cuda()
     prev = ops.attention_mma(mode)
     try:
@@ -136,15 +138,18 @@ def _attention_case(Lk, masked, mode):
 def test_attention_64_queries_per_wave_instantiations(Lk, masked):
     """aldm_attention_d32 at the BASELINE batch runs its QT = 2 instantiations (64 queries per wave), which the op tests'
     small batches never reach: self attention 1024 x 1024 (every UNet config) and the speech model's masked cross
-    attention over 512 keys.  Max-norm relative error <= 5e-5 vs the reference's einsum/softmax/einsum."""
+    attention over 512 keys.  Max-norm relative error <= 5e-6 vs the reference's einsum/softmax/einsum evaluated in fp64."""
     e = _attention_case(Lk, masked, 1)
     report(f"attention d32, 16 x 8 heads x 1024 queries x {Lk} keys{' masked' if masked else ''}, QT=2: rel err {e:.2e}")
-    assert e < 5e-5
+    assert log_err(e, fused_tol("f32"), "attention QT=2 f32") < fused_tol("f32")
 
 
 @pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("Lk,masked", [(1024, False), (512, True)])
 def test_attention_bf16_split_64_queries_per_wave_instantiations(Lk, masked, mode):
     """The same two shapes on the bf16 matrix cores: bf16x6 (mode 2) and the default bf16x3 (mode 3) — full key tiles, so the
-    software-pipelined kernel with 64 queries per wave, without and with a key mask."""
-    assert _attention_case(Lk, masked, mode) < 5e-5
+    software-pipelined kernel with 64 queries per wave, without and with a key mask.  Per-mode bars: 5e-6 / 5e-5."""
+    name = {2: "bf16x6", 3: "bf16x3"}[mode]
+    e = _attention_case(Lk, masked, mode)
+    report(f"attention d32 [{name}], 16 x 8 heads x 1024 queries x {Lk} keys{' masked' if masked else ''}, QT=2: rel err {e:.2e}")
+    assert log_err(e, fused_tol(name), f"attention QT=2 {name}") < fused_tol(name)
