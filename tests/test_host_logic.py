@@ -672,3 +672,59 @@ def test_reranker_without_clap_weights_is_flagged_and_warned():
     assert fresh.weights_loaded is False
     fresh.load_state_dict(own)
     assert fresh.weights_loaded is True
+
+
+@pytest.mark.timeout(900)
+def test_parity_on_checkpoint_script_reference_stage_and_checkpoint_loading(tmp_path):
+    """tools/parity_on_checkpoint.py on a random-init checkpoint written in the REFERENCE's format
+    (`torch.save({"state_dict": LatentDiffusion.state_dict()})`, pipeline.py:166-177, with the extra `model_ema.*` / `clap.*`
+    entries a released checkpoint carries): the reference stage runs the real `LatentDiffusion.generate_batch` from that file and
+    writes the cache; `build_model(ckpt_path=...)` — the path the hip stage takes — loads the same hot-path tensors bit for bit and
+    refuses a checkpoint with a hot-path tensor missing; without a GPU the hip stage refuses to run (exit code 2, no CPU path)."""
+    import subprocess
+    import sys
+    from oracle import refimport, weights
+    if not refimport.available():
+        pytest.skip("reference checkout not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    refimport.install()
+    import audioldm2.utils as ru
+    from audioldm2.latent_diffusion.models.ddpm import LatentDiffusion as RefLD
+    from audioldm2_amd.pipeline import build_model, default_audioldm_config
+    P = ru.default_audioldm_config("audioldm2-full")["model"]["params"]
+    cond = default_audioldm_config("audioldm2-full")["model"]["params"]["cond_stage_config"]
+    for k in cond:
+        cond[k]["params"]["device"] = "cpu"
+    P["cond_stage_config"], P["device"] = cond, "cpu"
+    torch.manual_seed(0)
+    sd = RefLD(**P).state_dict()
+    hot = {k: tuple(v.shape) for k, v in sd.items() if k.startswith(("model.diffusion_model.", "first_stage_model."))}
+    sd.update(weights.make_state_dict(hot, seed=3))
+    sd["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    sd["model_ema.decay"] = torch.tensor(0.9999)            # entries a released checkpoint has and the hot path ignores
+    sd["clap.model.logit_scale_a"] = torch.tensor(1.0)
+    ckpt = tmp_path / "random_init_reference_format.pth"
+    torch.save({"state_dict": sd, "global_step": 1}, ckpt)
+    cache = tmp_path / "ref.npz"
+    script = os.path.join(root, "tools", "parity_on_checkpoint.py")
+    r = subprocess.run([sys.executable, script, "--ckpt", str(ckpt), "--model", "audioldm2-full", "--steps", "1", "--batch", "1",
+                        "--stage", "reference", "--cache", str(cache)], capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    g = np.load(cache)
+    assert g["s1_b1_latent"].shape == (1, 8, 256, 16) and g["s1_b1_mel"].shape == (1, 1, 1024, 64)
+    assert g["s1_b1_wave"].shape == (1, 1, 163872) and np.isfinite(g["s1_b1_wave"]).all() and float(np.abs(g["s1_b1_wave"]).max()) > 0
+    # the hip stage's loader: same tensors, strict on the hot path
+    ld = build_model(ckpt_path=str(ckpt), model_name="audioldm2-full")
+    mine = ld.state_dict()
+    assert "scale_factor" in mine and "alphas_cumprod" in mine
+    for k in list(hot)[::97] + [k for k in ("scale_factor", "alphas_cumprod", "betas", "logvar") if k in mine]:
+        assert torch.equal(mine[k].cpu().float(), sd[k].float()), k
+    bad = dict(sd)
+    del bad[next(iter(hot))]
+    torch.save({"state_dict": bad}, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError, match="hot-path"):
+        build_model(ckpt_path=str(tmp_path / "bad.pth"), model_name="audioldm2-full")
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, script, "--ckpt", str(ckpt), "--stage", "hip", "--cache", str(cache), "--steps", "1",
+                            "--batch", "1"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "needs the MI355X" in r.stderr
