@@ -45,6 +45,13 @@ __global__ __launch_bounds__(512) void decode_linear_kernel(const float* __restr
                                                             const float* __restrict__ ln_b, float eps, int act,
                                                             const float* __restrict__ res, int ldr, float* __restrict__ y,
                                                             int ldy, int npass, int nl) {
+    // 80 KB at MT = 16: fits gfx950's 160 KB of LDS per CU (the 64 KB of gfx90a / gfx942 would not — this library is gfx950 only,
+    // and says so here instead of failing somewhere inside the build of an overridden ARCH)
+    static_assert(sizeof(float) * (MT * DL_PASS + DL_WAVES * MT * DL_CT + 2 * MT) <= 160 * 1024,
+                  "decode_linear_kernel: static LDS exceeds the 160 KB of a gfx950 CU");
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "csrc/decode.hip is written for gfx950 (160 KB LDS per CU); build with --offload-arch=gfx950"
+#endif
     __shared__ __attribute__((aligned(16))) float xs[MT][DL_PASS];
     __shared__ float red[DL_WAVES][MT][DL_CT];
     __shared__ float s_mean[MT], s_rstd[MT];
@@ -341,6 +348,10 @@ extern "C" int aldm_decode_attention(const float* qkv, int ldq, const int64_t* p
     ALDM_CHECK(qkv && pos && k_cache && v_cache && keymask && out && B > 0 && heads > 0, "aldm_decode_attention: bad args");
     ALDM_CHECK(n_tot > 0 && n_tot <= 1024, "aldm_decode_attention: %d cache positions (1..1024 supported)", n_tot);
     ALDM_CHECK(ldq >= 3 * heads * 64 && ldo >= heads * 64, "aldm_decode_attention: row pitch shorter than the row");
+    // the kernel reads qkv rows and the caches as f32x4 and writes out rows the same way
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) |
+                 reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (ldq & 3) == 0 && (ldo & 3) == 0,
+               "aldm_decode_attention: qkv / k_cache / v_cache / out must be 16-byte aligned with row pitches that are multiples of 4");
     hipLaunchKernelGGL(decode_attention_kernel, dim3(B * heads), dim3(1024), 0, (hipStream_t)stream, qkv, ldq, pos, k_cache,
                        v_cache, keymask, n_tot, heads, scale, out, ldo);
     ALDM_LAUNCH_CHECK("aldm_decode_attention");

@@ -434,8 +434,11 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             int os_nst = f_st - 300;
             if (os_nst == 0) os_nst = igemm_dma_os_default_stages(KT, d.split_parts);
             if (dma_os_eligible(p) && igemm_dma_os_config_ok(KT, os_nst, d.split_parts)) {
-                const char* env_rows_s = getenv("ALDM_OS_ROWS");   // tuning override (tools/os_probe.py): rows per block
-                const int env_rows = env_rows_s ? atoi(env_rows_s) : 0;
+                // tuning override (tools/os_probe.py): rows per block.  Read once (this runs per launch and per query)
+                static const int env_rows = [] {
+                    const char* e = getenv("ALDM_OS_ROWS");
+                    return e ? atoi(e) : 0;
+                }();
                 const int tn = cdiv(d.N, 128);
                 const int stages = cdiv(p.M, 32);
                 const int chunks = std::max(1, device_cus() / tn);   // one block per CU: the largest chunk count that still is one round

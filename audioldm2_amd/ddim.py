@@ -458,10 +458,12 @@ class DDIMSampler(object):
         x_cur, pred_x0 = ent["x_cur"], ent["pred_x0"]
         # the per-step draws are streamed by a drawer thread straight into the graph's static noise buffer (see _NoiseFeed)
         # While a run is in flight ONLY the drawer thread may consume torch's default CPU generator (it runs up to three 8-step
-        # chunks ahead).  A callback that draws from that generator itself declares it (`callback.uses_rng = True`): the draws
-        # then stay on the launching thread, one step at a time, sequenced with the callback exactly as in the reference
-        # (ALDM_NOISE_THREAD=0 forces the unthreaded feed for every run).
-        cb_rng = any(getattr(f, "uses_rng", False) for f in (callback, img_callback) if f is not None)
+        # chunks ahead).  In the reference ANY callback may draw from that generator between two steps, so a run WITH a callback
+        # keeps the draws on the launching thread, one step at a time, sequenced with the callback exactly as in the reference —
+        # unless the callback declares that it never draws (`callback.uses_rng = False`), which restores the threaded feed
+        # (ADVICE r3 + r4: opt-OUT, not opt-in — a silent interleaving gives a different noise stream with no diagnostic;
+        # INTEGRATION.md §5; ALDM_NOISE_THREAD=0 forces the unthreaded feed for every run).
+        cb_rng = any(getattr(f, "uses_rng", True) for f in (callback, img_callback) if f is not None)
         feed = _NoiseFeed(draw, total_steps, tuple(shape), mask is not None, temperature, dev, noise_buf=ent["noise_all"],
                           **({"threaded": False, "chunk": 1} if cb_rng else {}))
         feed.produce_next()

@@ -963,6 +963,15 @@ def decode_linear(x: torch.Tensor, w_kn: torch.Tensor, bias: Optional[torch.Tens
         assert res.shape == (M, N)
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
     g, b, eps = ln if ln is not None else (None, None, 0.0)
+    # the kernel takes raw pointers: a CPU / non-fp32 / strided bias or LayerNorm vector would be a fault or garbage, not an error
+    if bias is not None:
+        _chk(bias, "decode_linear.bias")
+        assert bias.numel() == N, f"decode_linear: bias has {bias.numel()} entries for N = {N}"
+    for t, nm in ((g, "ln gamma"), (b, "ln beta")):
+        if t is not None:
+            _chk(t, "decode_linear." + nm)
+            assert t.numel() == K, f"decode_linear: {nm} has {t.numel()} entries for K = {K}"
+    assert (g is None) == (b is None), "decode_linear: LayerNorm gamma and beta come together"
     _l.check(_l.load().aldm_decode_linear(x.data_ptr(), K, M, K, w_kn.data_ptr(), N, _p(bias), _p(g), _p(b), float(eps), act,
                                           _p(res), N, y.data_ptr(), N, _stream()), "decode_linear")
     return y

@@ -117,12 +117,20 @@ class Sequence2AudioMAE(nn.Module):
     def invalidate_packed(self):
         self._pk = None
 
+    def load_state_dict(self, *args, **kwargs):
+        """New weights invalidate every packed copy (prefill images and decode operands alike)."""
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
     def _packed(self):
         if self._pk is None:
             def conv1d(m):  # Conv1D [in, out] -> the Linear layout pack_conv expects
                 return ops.pack_conv(m.weight.detach().t().contiguous(), m.bias)
-            def kn(m):      # Conv1D's own [in, out] weight + bias: the operand of the single-position decode kernels
-                return (_f(m.weight), _f(m.bias))
+            def kn(m):      # Conv1D's own [in, out] weight + bias: the operand of the single-position decode kernels — a COPY, like
+                # every other packed operand: aliasing the live parameter would let an in-place weight update reach the decode path
+                # but not the (packed) prefill path (ADVICE r4)
+                return (_f(m.weight).clone(), _f(m.bias).clone())
             blocks = []
             for b in self.model.h:
                 blocks.append(dict(ln1=(_f(b.ln_1.weight), _f(b.ln_1.bias)), ln2=(_f(b.ln_2.weight), _f(b.ln_2.bias)),
@@ -195,7 +203,10 @@ class Sequence2AudioMAE(nn.Module):
         Z, n_tot = B * N_HEAD, keymask.shape[1]
         wpe = pk["wpe"].index_select(0, pos).expand(B, 1, N_EMBD).contiguous()
         h = ops.axpby(tok.contiguous(), wpe, 1.0, 1.0).view(B, N_EMBD)
-        if B <= ops.DECODE_MAX_ROWS and os.environ.get("ALDM_SEQGEN_DECODE", "fast") != "general":
+        fast = getattr(self, "_decode_fast", None)
+        if fast is None:   # (direct callers; generate() reads the switch once per call)
+            fast = os.environ.get("ALDM_SEQGEN_DECODE", "fast") != "general"
+        if B <= ops.DECODE_MAX_ROWS and fast:
             # B rows per Linear: weight streams, 5 launches per block (csrc/decode.hip) instead of the general path's ~17
             for l, blk in enumerate(pk["blocks"]):
                 qkv = ops.decode_linear(h, *blk["kn_attn"], ln=(*blk["ln1"], LN_EPS))
@@ -228,6 +239,7 @@ class Sequence2AudioMAE(nn.Module):
         if cond_dict is None:
             cond_dict = self.get_input(batch)
         x, mask, P = self.get_input_sequence_and_mask(cond_dict)
+        self._decode_fast = os.environ.get("ALDM_SEQGEN_DECODE", "fast") != "general"   # read once per generation, not per token
         B, steps = x.shape[0], self.mae_token_num
         n_tot = (P + steps + 3) // 4 * 4
         dev = x.device

@@ -459,6 +459,50 @@ def test_cfg_batched_equals_two_passes_and_graph_equals_eager(ld):
     assert torch.equal(eager["latent"], graph["latent"])
 
 
+def test_callback_draws_are_sequenced_with_the_step_noise_like_the_reference(ld):
+    """in the reference any callback may draw from torch's default generator between two steps (ddim.py:246-249 call it
+    right after p_sample_ddim's `torch.randn`, ddim.py:351).  A run that is GIVEN a callback therefore keeps the draws on the
+    launching thread, in the reference's order: x_T, then per step (step noise, whatever the callback draws) — checked through the
+    generator: after the run its state equals the state after exactly that sequence of CPU draws, and the latent equals the run
+    whose callback draws nothing of its own but is fed the same interleaved stream.  A callback that declares
+    `uses_rng = False` keeps the threaded feed (it must then really not draw)."""
+    from audioldm2_amd.ddim import DDIMSampler
+    B, S, shape = 2, 4, (8, 256, 16)
+    batch = cases.e2e_batch(B)
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(B)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    drawn = []
+
+    def cb(i):                      # an ordinary reference-style callback: draws without declaring anything
+        drawn.append(torch.randn(3))
+
+    def run(callback):
+        torch.manual_seed(77)
+        z, _ = DDIMSampler(ld).sample(S, B, shape, cond, eta=1.0, unconditional_guidance_scale=3.5,
+                                      unconditional_conditioning=uncond, verbose=False, callback=callback)
+        return z.clone(), torch.get_rng_state()
+    z_cb, st_cb = run(cb)
+    torch.manual_seed(77)            # the reference's order of draws, on the CPU
+    torch.randn((B,) + shape)
+    want = []
+    for _ in range(S):
+        torch.randn((B,) + shape)
+        want.append(torch.randn(3))
+    assert torch.equal(torch.get_rng_state(), st_cb), "generator not where the reference's draw order leaves it"
+    assert all(torch.equal(a, b) for a, b in zip(drawn, want)), "the callback saw other numbers than in the reference's order"
+    z_cb2, _ = run(cb)
+    assert torch.equal(z_cb, z_cb2)
+    quiet = lambda i: None
+    quiet.uses_rng = False           # declared: the threaded feed stays, and without a drawing callback the stream is x_T + S draws
+    z_q, st_q = run(quiet)
+    torch.manual_seed(77)
+    for _ in range(S + 1):
+        torch.randn((B,) + shape)
+    assert torch.equal(torch.get_rng_state(), st_q)
+    assert not torch.equal(z_q, z_cb)   # the callback's draws shift every later step's noise, as they do in the reference
+
+
 def test_pipeline_batch8_runs_and_is_batch_consistent(ld):
     """BASELINE config 2 shape (batch 8): finite output of the right shape; prompt 0 of the batch-8 run
     equals the batch-1 run on the same noise (samples are independent: no cross-sample coupling)."""
