@@ -629,6 +629,303 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
     }
 }
 
+
+// ---- round 5: the pre-split self-attention loop, re-scheduled -----------------------------------------------------------
+// The pipelined kernel above hangs its VALU work behind a FEW of a phase's MFMAs in logical units (a whole 8-value operand
+// split = 44 VALU, a whole rescale, a 16-value exponential block): in the shipped ISA the first five MFMAs of phase 1 are
+// followed by 34 / 45 / 51 / 33 / 21 VALU instructions, the next fifteen by none, and an 81-instruction register-copy tail
+// (pr_ = sc, kx = kxn) runs with the matrix pipe empty.  The launch holds ONE wave per SIMD (316 registers), so nothing else
+// fills those holes: SQ counters 32 % matrix-pipe busy, ~4300 cycles per key tile against 1536 of MFMA work
+// (profiles/r04_pmc_sq_bf16x6.txt, r05_attn_*).  An in-order wave overlaps the two pipes only when EVERY MFMA (32 cycles of
+// matrix pipe) is followed by about its own 32 cycles of independent VALU issue (~7 instructions).  This kernel is the same
+// arithmetic in the same order (bit-identical results) with
+//   * work ITEMS of <= ~11 VALU instructions — the split of one PAIR of probabilities into its three dwords, half a rescale,
+//     four exponentials with their running sum, half a running-max — dealt one (rarely two) per MFMA slot over the whole phase;
+//   * the operand split of the SECOND k-step's probabilities moved under the first k-step's P.V MFMAs (which do not read it),
+//     the running max behind it, the exponentials under the second k-step: phase 2 no longer opens on a wait for the scores;
+//   * no register copies: scores ping-pong between two buffers (tile j's Q.K^T lands in the one whose probabilities the
+//     previous P.V has consumed), K and V^T tiles land in the two register sets their MFMAs read, alternately — the key loop is
+//     unrolled by two on the tile parity;
+//   * tile 0's Q.K^T and softmax run as a prologue instead of a whole iteration multiplying a zero P_{-1}.
+// Only for what the UNet's self-attention launches: K / V^T pre-split by the QKV epilogue, no mask, Lk % 32 == 0.
+template <int N, int S>
+constexpr int item_slot(int k, int base) { return base + (k * S) / N; }
+
+template <int QT, int NP>
+__global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
+    const float* __restrict__ q, const void* __restrict__ k_img, const void* __restrict__ vt_img, float* __restrict__ out,
+    int Lq, int Lk, int ldq, int heads, int ldo, float scale, void* __restrict__ out_split, int split_c, int parts) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
+    if (q0 >= Lq) return;  // wave-uniform
+
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
+    constexpr int PB_[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
+    constexpr int NMF = NPROD * 2 * QT;   // MFMAs of one product of a tile; MFMA i = (k-step i / (NPROD*QT), product, query tile i % QT)
+    constexpr int HALF = NMF / 2;         // ... the first HALF of them are k-step 0
+
+    // Q^T operands, pre-scaled by scale * log2(e) (scores in log2 units), k-step s covers d = 16*lh + 8*s .. + 7
+    const float qscale = scale * 1.44269504088896340736f;
+    bf16x8 qx[QT][2][3];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = min(q0 + 32 * t + l31, Lq - 1);
+        const float* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32 + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 8 * s), x1 = *reinterpret_cast<const f32x4*>(qp + 8 * s + 4);
+            float x8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x8[e] = x0[e] * qscale;
+                x8[4 + e] = x1[e] * qscale;
+            }
+            split8_np<NP>(x8, qx[t][s]);
+        }
+    }
+
+    // the images of this (sample, head): k rows [key][heads][NP][32] bf16, v tiles [tile][NP][32 dims][32 keys] bf16
+    const char* kimg = reinterpret_cast<const char*>(k_img) + ((int64_t)b * Lk * heads + h) * (64 * NP);
+    const char* vimg = reinterpret_cast<const char*>(vt_img) + ((int64_t)b * heads + h) * (Lk >> 5) * (int64_t)(NP * 2048);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(kimg), 0, ((Lk - 1) * heads + 1) * (64 * NP), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(vimg), 0, (Lk >> 5) * NP * 2048, 0x00020000);
+    const int koff = l31 * heads * (64 * NP) + lh * 32;
+    const int voff = l31 * 64 + lh * 16;
+    const int nt = Lk >> 5;
+    const int t_last = nt - 1;    // prefetches past the end re-read the last tile (never used)
+
+    u32x4 Kr[2][2][NP], Vr[2][2][NP];   // [tile parity][k-step][part]: the landing registers ARE the MFMA operands
+    u32x4 px[QT][2][NP];                // P^T operands of the tile whose P.V runs next
+    f32x16 S[2][QT];                    // [tile parity]: scores, then (in place) probabilities
+    f32x16 oT[QT];
+    float m_run[QT], l_run[QT], alpha[QT], m_new[QT], tmax[QT], psum[QT];
+
+    auto load_k = [&](auto pc, int tile) {
+        constexpr int P = decltype(pc)::value;
+        const int sk = __builtin_amdgcn_readfirstlane(min(tile, t_last) * 32 * heads * (64 * NP));
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Kr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * s + 64 * p, sk, 0);
+    };
+    auto load_v = [&](auto pc, int tile) {
+        constexpr int P = decltype(pc)::value;
+        const int sv = __builtin_amdgcn_readfirstlane(min(tile, t_last) * (NP * 2048));
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Vr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff + 32 * s + 2048 * p, sv, 0);
+    };
+
+    // ---- work items (each <= ~11 VALU instructions) ----
+    // SP: probabilities 8s + 2p, 8s + 2p + 1 of query tile t -> dword p of the NP parts of px[t][s] (split8's arithmetic)
+    auto item_sp = [&](auto pc, int t, int s, int p) {
+        constexpr int P = decltype(pc)::value;
+        const float x0 = S[P][t][8 * s + 2 * p], x1 = S[P][t][8 * s + 2 * p + 1];
+        if constexpr (NP == 3) {
+            const unsigned a0 = __builtin_bit_cast(unsigned, x0), a1 = __builtin_bit_cast(unsigned, x1);
+            const float r0 = x0 - __builtin_bit_cast(float, a0 & 0xFFFF0000u), r1 = x1 - __builtin_bit_cast(float, a1 & 0xFFFF0000u);
+            const unsigned b0 = __builtin_bit_cast(unsigned, r0), b1 = __builtin_bit_cast(unsigned, r1);
+            const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xFFFF0000u), s1 = r1 - __builtin_bit_cast(float, b1 & 0xFFFF0000u);
+            px[t][s][0][p] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+            px[t][s][1][p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+            px[t][s][2][p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+        } else {   // (hi, mid) rounded to nearest: split8_rn2's arithmetic
+            using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+            const __bf16 m0 = (__bf16)(x0 - (float)h0), m1 = (__bf16)(x1 - (float)h1);
+            px[t][s][0][p] = __builtin_bit_cast(unsigned, bf16x2{h0, h1});
+            px[t][s][1][p] = __builtin_bit_cast(unsigned, bf16x2{m0, m1});
+        }
+    };
+    // RS: half hh of O^T of query tile t times alpha
+    auto item_rs = [&](int t, int hh) {
+#pragma unroll
+        for (int e = 8 * hh; e < 8 * hh + 8; ++e) oT[t][e] *= alpha[t];
+    };
+    // MX: running max of query tile t, first / second 8 scores (+ the cross-half exchange, alpha, m_run)
+    auto item_mx = [&](auto pc, int t, int a) {
+        constexpr int P = decltype(pc)::value;
+        if (a == 0) {
+            float mx = S[P][t][0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) mx = fmaxf(mx, S[P][t][r]);
+            tmax[t] = mx;
+        } else {
+            float mx = tmax[t];
+#pragma unroll
+            for (int r = 8; r < 16; ++r) mx = fmaxf(mx, S[P][t][r]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false,
+                                                             false);
+            mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            m_new[t] = fmaxf(m_run[t], mx);
+            alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new[t]);   // 0 on the first tile (m_run = -inf)
+            m_run[t] = m_new[t];
+        }
+    };
+    // EX: probabilities 4g .. 4g + 3 of query tile t (in place) and their part of the row sum, in the scores' order
+    auto item_ex = [&](auto pc, int t, int g) {
+        constexpr int P = decltype(pc)::value;
+        float ps = g == 0 ? 0.f : psum[t];
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(S[P][t][r] - m_new[t]);
+            S[P][t][r] = pv;
+            ps += pv;
+        }
+        psum[t] = ps;
+        if (g == 3) l_run[t] = l_run[t] * alpha[t] + ps;
+    };
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma_qk = [&](auto pc, auto ic) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int i = decltype(ic)::value;
+        constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
+        S[P][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Kr[P][s][PA_[pr]]), qx[t][s][PB_[pr]],
+                                                          (s == 0 && pr == 0) ? zero16 : S[P][t], 0, 0, 0);
+    };
+    auto mfma_pv = [&](auto vc, auto ic) {   // vc: parity of the V tile (= of the P tile)
+        constexpr int P = decltype(vc)::value;
+        constexpr int i = decltype(ic)::value;
+        constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
+        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Vr[P][s][PA_[pr]]),
+                                                        __builtin_bit_cast(bf16x8, px[t][s][PB_[pr]]), oT[t], 0, 0, 0);
+    };
+
+    // item lists of a steady-state tile j (parity P; Q = the other parity = tile j - 1), dealt evenly over the phase's MFMA slots:
+    //   phase 1 (Q.K^T of tile j)  : SP(t, 0, p) of P_{j-1} x 4 QT, the first MV of the SP(t, 1, p), RS(t, hh) x 2 QT, load V_j
+    //   phase 2 (P.V of tile j - 1): load K_{j+2}, the other 4 QT - MV SP(t, 1, p) — before the first k-step-1 MFMA (slot HALF)
+    //                                reads them —, MX(t, a) of S_j x 2 QT, EX(t, g) of S_j x 4 QT
+    // MV = 2 QT balances the two phases (QT = 2, 3 parts: 17 items = ~172 / ~184 VALU instructions per 24 slots).
+#ifndef ALDM_ATTN_MVQ
+#define ALDM_ATTN_MVQ 2   // (A/B builds: 0 .. 4 of the four k-step-1 pairs of every query tile)
+#endif
+    constexpr int MV = ALDM_ATTN_MVQ * QT;
+    static_assert(MV >= 0 && MV <= 4 * QT, "SP items of k-step 1 moved into phase 1");
+    constexpr int N1 = 4 * QT + MV + 2 * QT + 1;
+    constexpr int N2 = 1 + (4 * QT - MV) + 2 * QT + 4 * QT;
+    static_assert(MV == 4 * QT || item_slot<N2, NMF>(4 * QT - MV, 0) < HALF, "P operands of k-step 1 must be complete before its first MFMA");
+    auto run_item1 = [&](auto pc, auto kc, int j) {
+        constexpr int P = decltype(pc)::value, Q = 1 - P;
+        constexpr int k = decltype(kc)::value;
+        using QC = std::integral_constant<int, Q>;
+        if constexpr (k < 4 * QT) item_sp(QC{}, k / 4, 0, k % 4);
+        else if constexpr (k < 4 * QT + MV) item_sp(QC{}, (k - 4 * QT) / 4, 1, (k - 4 * QT) % 4);
+        else if constexpr (k < 6 * QT + MV) item_rs((k - 4 * QT - MV) / 2, (k - 4 * QT - MV) % 2);
+        else load_v(pc, j);
+    };
+    auto run_item2 = [&](auto pc, auto kc, int j) {
+        constexpr int P = decltype(pc)::value, Q = 1 - P;
+        constexpr int k = decltype(kc)::value;
+        constexpr int NSP = 4 * QT - MV;
+        using QC = std::integral_constant<int, Q>;
+        if constexpr (k == 0) load_k(pc, j + 2);   // Kr[P] is free: every Q.K^T MFMA of tile j has been issued and has read it
+        else if constexpr (k < 1 + NSP) item_sp(QC{}, (MV + k - 1) / 4, 1, (MV + k - 1) % 4);
+        else if constexpr (k < 1 + NSP + 2 * QT) item_mx(pc, (k - 1 - NSP) / 2, (k - 1 - NSP) % 2);
+        else item_ex(pc, (k - 1 - NSP - 2 * QT) / 4, (k - 1 - NSP - 2 * QT) % 4);
+    };
+
+    auto body = [&](auto pc, int j) {
+        constexpr int P = decltype(pc)::value, Q = 1 - P;
+        // phase 1
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mfma_qk(pc, ic);
+            static_for<0, N1>([&](auto kc) {
+                if constexpr (item_slot<N1, NMF>(decltype(kc)::value, 0) == i) run_item1(pc, kc, j);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // phase 2
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mfma_pv(std::integral_constant<int, Q>{}, ic);
+            static_for<0, N2>([&](auto kc) {
+                if constexpr (item_slot<N2, NMF>(decltype(kc)::value, 0) == i) run_item2(pc, kc, j);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[t][e] = 0.f;
+        m_run[t] = -INFINITY;
+        l_run[t] = 0.f;
+        alpha[t] = 1.f;
+    }
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // prologue: tile 0 (parity 0): its Q.K^T and softmax, nothing to overlap with yet; K_1, V_0 in flight behind K_0
+    load_k(P0{}, 0);
+    load_k(P1{}, 1);
+    load_v(P0{}, 0);
+    static_for<0, NMF>([&](auto ic) { mfma_qk(P0{}, ic); });
+    __builtin_amdgcn_sched_barrier(0);
+    load_k(P0{}, 2);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        item_mx(P0{}, t, 0);
+        item_mx(P0{}, t, 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) item_ex(P0{}, t, g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    int j = 1;
+    for (; j + 1 < nt; j += 2) {
+        body(P1{}, j);
+        body(P0{}, j + 1);
+    }
+    // the last tile's probabilities: split, rescale, P.V — un-overlapped
+    auto tail = [&](auto pc) {   // pc: parity of the LAST tile
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) item_sp(pc, t, s, p);
+            item_rs(t, 0);
+            item_rs(t, 1);
+        }
+        static_for<0, NMF>([&](auto ic) { mfma_pv(pc, ic); });
+    };
+    if (j < nt) {   // odd tile left (parity 1)
+        body(P1{}, j);
+        tail(P1{});
+    } else {
+        tail(P0{});
+    }
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + 32 * t + l31;
+        if (qi < Lq) {
+            float* op = out ? out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
+                if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
+                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
+            }
+        }
+    }
+}
+
 }  // namespace aldm
 
 using namespace aldm;
@@ -751,16 +1048,34 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
     const float* kf = reinterpret_cast<const float*>(k_split);
     const float* vf = reinterpret_cast<const float*>(vt_split);
     const int split_c = heads * 32;
+    // the re-scheduled loop (attention_d32_presplit2_kernel, same arithmetic and results): ALDM_ATTN_SCHED=0 keeps the round-3 / 4
+    // pipelined kernel for A/Bs (tools/attn_probe.py)
+    static const bool sched2 = [] {
+        const char* e = getenv("ALDM_ATTN_SCHED");
+        return e == nullptr || e[0] != '0';
+    }();
 #define ALDM_ATTN_PRE(Q_, P_)                                                                                          \
     hipLaunchKernelGGL((attention_d32_pipe_kernel<false, Q_, P_, true>), grid, dim3(256), 0, st, q, kf, vf, out, Lq, Lk, ldq, \
                        heads, 0, ldo, nullptr, scale, out_split, split_c, parts)
-    if (parts == 2) {
+#define ALDM_ATTN_PRE2(Q_, P_)                                                                                         \
+    hipLaunchKernelGGL((attention_d32_presplit2_kernel<Q_, P_>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk, ldq, \
+                       heads, ldo, scale, out_split, split_c, parts)
+    if (sched2) {
+        if (parts == 2) {
+            if (qt2) ALDM_ATTN_PRE2(2, 2);
+            else ALDM_ATTN_PRE2(1, 2);
+        } else {
+            if (qt2) ALDM_ATTN_PRE2(2, 3);
+            else ALDM_ATTN_PRE2(1, 3);
+        }
+    } else if (parts == 2) {
         if (qt2) ALDM_ATTN_PRE(2, 2);
         else ALDM_ATTN_PRE(1, 2);
     } else {
         if (qt2) ALDM_ATTN_PRE(2, 3);
         else ALDM_ATTN_PRE(1, 3);
     }
+#undef ALDM_ATTN_PRE2
 #undef ALDM_ATTN_PRE
     ALDM_LAUNCH_CHECK("aldm_attention_d32_presplit");
     return 0;

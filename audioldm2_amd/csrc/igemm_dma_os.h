@@ -36,6 +36,10 @@
                            // fragment reads
 #endif
 
+#ifndef ALDM_OS_GEGLU_PACK
+#define ALDM_OS_GEGLU_PACK 1   // 0: one GELU per accumulator register (round 4), for A/Bs
+#endif
+
 namespace aldm {
 
 constexpr int os_stage_slots(int KT, int NP) { return KT * 128 * NP; }   // 16-byte slots of one stage: 32 rows x K x NP parts
@@ -171,6 +175,26 @@ void igemm_dma_os_kernel(const IgemmK p) {
         if (geglu) {
             // y = (value + b_v) * gelu(gate + b_g) (attention.py:37-45): the gate of value lane lc sits 8 lanes up in the same
             // 16-lane row -> one DPP row rotation; lanes lc < 8 then hold a 32 x 8 tile of outputs
+#if ALDM_OS_GEGLU_PACK
+            // Every lane runs every VALU instruction, but only the value lanes (lc < 8) keep a result: evaluating gelu(gate) once
+            // per accumulator wastes half of each GELU.  Instead ONE GELU per register index i serves both row tiles: the gate lanes
+            // evaluate their own gate of row tile 0, the value lanes the gate of row tile 1 (fetched from 8 lanes up by a DPP row
+            // rotation whose bank mask writes the value lanes only) — 4 GELUs per stage instead of 8, same values, same results.
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x0 = acc[0][i] + g_bias, x1 = acc[1][i] + g_bias;
+                // lanes lc < 8 (banks 0, 1 of every 16-lane row): x1 of lane lc + 8 = the gate of row tile 1; lanes lc >= 8: own x0
+                const float z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x0), __builtin_bit_cast(int, x1),
+                                                                                      0x128 /* row_ror:8 */, 0xf, 0x3, false));
+                const float gz = act_apply(z, gate_act, 0.f);
+                const float g0 = __builtin_bit_cast(   // gelu(gate of row tile 0) from the gate lanes
+                    float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+                if (lc < 8) {
+                    stg[(lg * 4 + i) * 8 + lc] = x0 * g0;
+                    stg[(16 + lg * 4 + i) * 8 + lc] = x1 * gz;
+                }
+            }
+#else
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -181,6 +205,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
                     const float y = x * act_apply(xg, gate_act, 0.f);
                     if (lc < 8) stg[(rt * 16 + lg * 4 + i) * 8 + lc] = y;
                 }
+#endif
             const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[g_er * 8 + g_ec]);
             const int m = m0 + g_er;
             if (m < p.M && g_cok) {
