@@ -32,16 +32,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // erf GELU 0.5 v (1 + erf(v / sqrt 2)) without libm: Abramowitz-Stegun 7.1.26 for erfc(|z|) = poly(t) exp(-z^2), t = 1/(1 + p|z|)
 // (|error| <= 1.5e-7), evaluated as 1 + erf(z) = erfc(-z) = { poly e : z < 0 ; 2 - poly e : z >= 0 } so the negative tail has
-// no cancellation.  Max |error| vs the fp64 GELU 4.2e-7 over [-12, 12] (ATen's fp32 F.gelu: 1.2e-6), 1.9e-7 relative to
-// max(|v|, 1); ~15 VALU instead of ocml erff's ~50 (both of its branches execute in a divergent wave) — the GEGLU epilogue
-// is VALU bound on this (tools/dma_ablate_shapes.py).
+// no cancellation.  Max |error| vs the fp64 GELU 3.3e-7 over [-12, 12] (ATen's fp32 F.gelu: 1.2e-6), 1.6e-7 relative to
+// max(|v|, 1); ocml erff costs ~50 VALU (both of its branches execute in a divergent wave) — the GEGLU epilogue is VALU bound on
+// this (tools/dma_ablate_shapes.py).
 __device__ __forceinline__ float gelu_erf_fast(float v) {
-    const float z = v * 0.70710678118654752440f;
-    const float a = fabsf(z);
-    const float t = __frcp_rn(1.0f + 0.3275911f * a);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float pe = poly * __expf(-(a * a));
-    return 0.5f * v * (z < 0.0f ? pe : 2.0f - pe);
+    // 16 VALU instructions (round 4: ~23 — the library is built with -ffp-contract=off, so the Horner steps are explicit FMAs here,
+    // and the sign select is folded away: 0.5 v (1 + erf z) = max(v, 0) - 0.5 |v| poly(t) exp(-z^2) for either sign of v).  In the
+    // GEGLU epilogues every one of these instructions is issue time the matrix pipe does not overlap.
+    const float a = fabsf(v) * 0.70710678118654752440f;                       // |z|
+    const float t = __frcp_rn(__builtin_fmaf(0.3275911f, a, 1.0f));
+    float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    q = __builtin_fmaf(t, q, 1.421413741f);
+    q = __builtin_fmaf(t, q, -0.284496736f);
+    q = __builtin_fmaf(t, q, 0.254829592f);
+    const float pe = (t * q) * __builtin_amdgcn_exp2f((a * a) * -1.44269504088896340736f);   // erfc(|z|)
+    return __builtin_fmaf(fabsf(v) * -0.5f, pe, fmaxf(v, 0.0f));
 }
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {

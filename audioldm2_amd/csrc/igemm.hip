@@ -271,7 +271,7 @@ static bool dma_os_eligible(const IgemmK& p) {
     if (d.OH != d.H || d.OW != d.W || d.K != p.Cin || d.K % 32 != 0 || d.out_mul > 0 || d.batch > 1) return false;
     if (d.epi_mode == ALDM_EPI_QKV && d.qkv_c % 128 != 0) return false;
     // its epilogue is the vector form only: no row bias / output activation / accumulation, float4-addressable fp32 operands
-    if (d.rowbias || d.accumulate || (d.act != ALDM_ACT_NONE && d.epi_mode != ALDM_EPI_GEGLU)) return false;
+    if (d.rowbias || d.accumulate || d.act != ALDM_ACT_NONE) return false;   // (GEGLU: the erf gate only — act == NONE; T5's tanh gate has K = 1024)
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if ((d.N & 3) != 0 || (d.ldo & 3) != 0 || !al16(d.out) || !al16(d.res)) return false;
     return true;

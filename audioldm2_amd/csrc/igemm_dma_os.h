@@ -46,7 +46,15 @@ constexpr int os_stage_slots(int KT, int NP) { return KT * 128 * NP; }   // 16-b
 constexpr int OS_EPI_SLOTS = 512;                                         // epilogue staging: 8 waves x 16 x 16 floats = 8 KB
 constexpr int os_lds_bytes(int KT, int NST, int NP) { return (NST * os_stage_slots(KT, NP) + OS_EPI_SLOTS) * 16; }
 
-template <int KT, int NST, int NP>
+// EPI (round 5): the epilogue a launch needs is known on the host, so it is a template parameter — the round-4 kernel chose among
+// the plain / GEGLU / QKV forms, 2- or 3-part images and the gate activation with wave-uniform RUNTIME branches inside every
+// 32-row stage (a dozen s_cbranch per 16x16 tile, each with its v_cmp / s_and and the scheduling fence a branch is), and loaded the
+// residual with a global_load -> s_waitcnt vmcnt(0) pair in the middle of the epilogue: a full drain (the ring's LDS-DMA included)
+// plus an L2 round trip per tile, per stage.  Now: one straight-line epilogue per instantiation, the image format is NP, and the
+// residual rows of stage t are fetched at the TOP of stage t — they land under the stage's MFMAs.
+enum { OS_EPI_PLAIN = 0, OS_EPI_GEGLU = 1, OS_EPI_QKV = 2 };
+
+template <int KT, int NST, int NP, int EPI>
 __global__ __launch_bounds__(512, 2)
 void igemm_dma_os_kernel(const IgemmK p) {
     constexpr int STG = os_stage_slots(KT, NP);
@@ -108,7 +116,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
 
     issue_stage(0);
     // ---- the wave's 16 weight columns, all of K, into registers: k-tile kt, k-group lg -> octet 4 kt + lg of column wcol ----
-    const bool geglu = d.epi_mode == ALDM_EPI_GEGLU;
+    constexpr bool geglu = EPI == OS_EPI_GEGLU;
     const int g64 = wave >> 2, j8 = wave & 3;   // GEGLU: 64-column group of the packed image, 8-column sub-slab
     bf16x8 bw[KT][NP];
     {
@@ -129,7 +137,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
         if (s < nstg) issue_stage(s);
 
     // ---- epilogue constants: the columns of a block never change ----
-    const bool qkv = d.epi_mode == ALDM_EPI_QKV;
+    constexpr bool qkv = EPI == OS_EPI_QKV;
     const int seg = qkv ? n0 / d.qkv_c : 0;               // q | k | v segment of the fused projection (whole 128-column slabs)
     float* outp = d.out;
     void* simg = d.out_split;
@@ -151,19 +159,35 @@ void igemm_dma_os_kernel(const IgemmK p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) bias4[c] = d.bias[min(ncol + c, d.N - 1)];
     }
+    const bool has_res = EPI == OS_EPI_PLAIN && d.res != nullptr;
+    const bool lrelu_img = EPI == OS_EPI_PLAIN && d.out_split_act == ALDM_ACT_LRELU;
     // GEGLU: lane column lc < 8 -> value column, lc >= 8 -> its gate column; outputs leave through lanes of an 8-column tile
     const int g_pcol = n0 + g64 * 64 + j8 * 8 + (lc < 8 ? lc : 32 + (lc - 8));
     const float g_bias = (geglu && d.bias && g_pcol < d.N) ? d.bias[g_pcol] : 0.f;
     const int g_er = lane >> 1, g_ec = (lane & 1) * 4;
     const int g_ncol_o = ((n0 + g64 * 64) >> 1) + j8 * 8 + g_ec;
     const bool g_cok = n0 + g64 * 64 + j8 * 8 + g_ec < d.N;
-    const int gate_act = d.act == ALDM_ACT_GELU_TANH ? ALDM_ACT_GELU_TANH : ALDM_ACT_GELU;
 
     // fragment addressing: row lc of row tile rt, k-tile kt, k-group lg -> octet lg of the k-tile
     const int foff = lc * 4 + (lg ^ ((4 - ((lc >> 2) & 3)) & 3));
     constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};   // smallest partial products first
     constexpr int PB_[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};   // (the order of igemm_dma_kernel)
     float* const stg = reinterpret_cast<float*>(&smem[NST * STG]) + wave * 256;             // this wave's 1 KB of staging
+
+    // residual rows of a stage, fetched a whole K loop before their epilogue reads them (clamped address when out of range)
+    f32x4 resv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto prefetch_res = [&](int t) {
+        if constexpr (EPI == OS_EPI_PLAIN) {
+            if (has_res) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int m = r0 + t * 32 + rt * 16 + er;
+                    const bool ok = m < p.M && ncol < d.N;
+                    resv[rt] = *reinterpret_cast<const f32x4*>(d.res + (ok ? (int64_t)m * d.ldo + ncol : 0));
+                }
+            }
+        }
+    };
 
     f32x4 acc[2];
     auto epilogue = [&](int t) {
@@ -172,9 +196,10 @@ void igemm_dma_os_kernel(const IgemmK p) {
             return;
         }
         const int m0 = (ALDM_OS_ABLATE & 8) ? p.M + (p.M == -12345 ? 0 : 64) : r0 + t * 32;   // (ablation: every row out of range)
-        if (geglu) {
+        if constexpr (geglu) {
             // y = (value + b_v) * gelu(gate + b_g) (attention.py:37-45): the gate of value lane lc sits 8 lanes up in the same
-            // 16-lane row -> one DPP row rotation; lanes lc < 8 then hold a 32 x 8 tile of outputs
+            // 16-lane row -> one DPP row rotation; lanes lc < 8 then hold a 32 x 8 tile of outputs.  (erf GELU: the tanh-gated
+            // form of T5 has K = 1024 and never runs here — host checked.)
 #if ALDM_OS_GEGLU_PACK
             // Every lane runs every VALU instruction, but only the value lanes (lc < 8) keep a result: evaluating gelu(gate) once
             // per accumulator wastes half of each GELU.  Instead ONE GELU per register index i serves both row tiles: the gate lanes
@@ -186,7 +211,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
                 // lanes lc < 8 (banks 0, 1 of every 16-lane row): x1 of lane lc + 8 = the gate of row tile 1; lanes lc >= 8: own x0
                 const float z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x0), __builtin_bit_cast(int, x1),
                                                                                       0x128 /* row_ror:8 */, 0xf, 0x3, false));
-                const float gz = act_apply(z, gate_act, 0.f);
+                const float gz = gelu_erf_fast(z);
                 const float g0 = __builtin_bit_cast(   // gelu(gate of row tile 0) from the gate lanes
                     float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
                 if (lc < 8) {
@@ -202,7 +227,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
                     const float x = acc[rt][i] + g_bias;
                     const float xg = __builtin_bit_cast(
                         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-                    const float y = x * act_apply(xg, gate_act, 0.f);
+                    const float y = x * gelu_erf_fast(xg);
                     if (lc < 8) stg[(rt * 16 + lg * 4 + i) * 8 + lc] = y;
                 }
 #endif
@@ -210,54 +235,62 @@ void igemm_dma_os_kernel(const IgemmK p) {
             const int m = m0 + g_er;
             if (m < p.M && g_cok) {
                 if (d.out) *reinterpret_cast<f32x4*>(d.out + (int64_t)m * d.ldo + g_ncol_o) = v;
-                if (d.out_split) split_store4(d.out_split, m, d.out_split_c, g_ncol_o, v, d.split_parts);
+                if (d.out_split) split_store4_t<NP>(d.out_split, m, d.out_split_c, g_ncol_o, v);
             }
             return;
-        }
-        if (qkv && seg == 2) {
-            // v: transposed per (sample, head, 32-key tile) straight from the accumulators.  The image keeps the 32 keys of a
-            // tile in the order the attention kernel's P operand has them (the 32x32 MFMA accumulator rows: 16-byte chunk 2 s + h
-            // of a dim's 64-byte row = keys 16 s + 4 h + {0..3, 8..11}); lane (column lc, k-group lg) holds keys 4 lg .. 4 lg + 3
-            // of row tile rt = half of chunk 2 rt + (lg & 1)
-            char* vt = reinterpret_cast<char*>(d.vt_split);
-            const int heads = d.qkv_c >> 5, parts = d.split_parts;
-            const int tiles = d.qkv_rows >> 5;
-            if (m0 >= p.M) return;
-            const int b = m0 / d.qkv_rows, tl = (m0 - b * d.qkv_rows) >> 5;
-            const int cc = n0 - 2 * d.qkv_c + wave * 16 + lc;
-            const int h = cc >> 5, dd = cc & 31;
-            char* base = vt + ((((int64_t)b * heads + h) * tiles + tl) * parts) * 2048 + dd * 64 + (lg & 1) * 16 + (lg >> 1) * 8;
+        } else {
+            if constexpr (qkv) {
+                if (seg == 2) {
+                    // v: transposed per (sample, head, 32-key tile) straight from the accumulators.  The image keeps the 32 keys of a
+                    // tile in the order the attention kernel's P operand has them (the 32x32 MFMA accumulator rows: 16-byte chunk 2 s + h
+                    // of a dim's 64-byte row = keys 16 s + 4 h + {0..3, 8..11}); lane (column lc, k-group lg) holds keys 4 lg .. 4 lg + 3
+                    // of row tile rt = half of chunk 2 rt + (lg & 1)
+                    char* vt = reinterpret_cast<char*>(d.vt_split);
+                    const int heads = d.qkv_c >> 5;
+                    const int tiles = d.qkv_rows >> 5;
+                    if (m0 >= p.M) return;
+                    const int b = m0 / d.qkv_rows, tl = (m0 - b * d.qkv_rows) >> 5;
+                    const int cc = n0 - 2 * d.qkv_c + wave * 16 + lc;
+                    const int h = cc >> 5, dd = cc & 31;
+                    char* base = vt + ((((int64_t)b * heads + h) * tiles + tl) * NP) * 2048 + dd * 64 + (lg & 1) * 16 + (lg >> 1) * 8;
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        u32x2 part[3];
+                        split4_parts(acc[rt], part, NP);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(base + q * 2048 + rt * 32) = part[q];
+                    }
+                    return;
+                }
+            }
+            // plain / q / k: transpose each 16x16 tile through the wave's staging so that a lane owns 4 consecutive columns, then
+            //   v = acc + bias; v += res; v *= alpha; out = v; out_split = split([leaky_relu] v)        (igemm_epilogue's order)
+            // Both row tiles' values are finished BEFORE the first store: a store counts in vmcnt like a load, so reading the second
+            // tile's prefetched residual after the first tile's stores would wait for those stores to be acknowledged.
+            f32x4 v[2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                u32x2 part[3];
-                split4_parts(acc[rt], part, parts);
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (q < parts) *reinterpret_cast<u32x2*>(base + q * 2048 + rt * 32) = part[q];
+                for (int i = 0; i < 4; ++i) stg[(lg * 4 + i) * 16 + lc] = acc[rt][i];
+                v[rt] = *reinterpret_cast<const f32x4*>(&stg[er * 16 + ec]);
+                v[rt] += bias4;
+                if (has_res) v[rt] += resv[rt];
+                v[rt] *= d.alpha;
             }
-            return;
-        }
-        // plain / q / k: transpose each 16x16 tile through the wave's staging so that a lane owns 4 consecutive columns, then
-        //   v = acc + bias; v += res; v *= alpha; out = v; out_split = split([leaky_relu] v)        (igemm_epilogue's order)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < 2; ++rt) {
+                const int m = m0 + rt * 16 + er;
+                const bool ok = m < p.M && ncol < d.N;
+                const int64_t off = ok ? (int64_t)m * d.ldo + (ncol - col_shift) : 0;
+                if (ok) {
+                    if (outp) *reinterpret_cast<f32x4*>(outp + off) = v[rt];
+                    if (simg) {
+                        if (lrelu_img) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) stg[(lg * 4 + i) * 16 + lc] = acc[rt][i];
-            f32x4 v = *reinterpret_cast<const f32x4*>(&stg[er * 16 + ec]);
-            const int m = m0 + rt * 16 + er;
-            const bool ok = m < p.M && ncol < d.N;
-            const int64_t off = ok ? (int64_t)m * d.ldo + (ncol - col_shift) : 0;
-            v += bias4;
-            if (d.res && !qkv) v += *reinterpret_cast<const f32x4*>(d.res + off);
-            v *= d.alpha;
-            if (ok) {
-                if (outp) *reinterpret_cast<f32x4*>(outp + off) = v;
-                if (simg) {
-                    if (d.out_split_act == ALDM_ACT_LRELU) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.0f ? v[c] : v[c] * d.out_split_slope;
+                            for (int c = 0; c < 4; ++c) v[rt][c] = v[rt][c] > 0.0f ? v[rt][c] : v[rt][c] * d.out_split_slope;
+                        }
+                        split_store4_t<NP>(simg, m, simg_c, ncol - col_shift, v[rt]);
                     }
-                    split_store4(simg, m, simg_c, ncol - col_shift, v, d.split_parts);
                 }
             }
         }
@@ -270,6 +303,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
 
     for (int t = 0; t < nstg; ++t) {
         if (late && t > 0) epilogue(t - 1);   // under the partner wave's MFMAs of stage t
+        prefetch_res(t);                      // this stage's residual rows: in flight under its K loop (older than the stage DMA below)
         const bool more = t + NST - 1 < nstg;
         if (more && !(ALDM_OS_ABLATE & 1)) issue_stage(t + NST - 1);   // into the buffer of stage t - 1: every wave is past its barrier
         const u32x4* sa = &smem[(t % NST) * STG];

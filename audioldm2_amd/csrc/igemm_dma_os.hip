@@ -18,9 +18,15 @@ int igemm_dma_os_default_stages(int KT, int parts) {
 }
 
 int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+    // the epilogue form is a template parameter (igemm_dma_os.h, EPI): chosen here from the descriptor
+    const int epi = p.d.epi_mode == ALDM_EPI_GEGLU ? OS_EPI_GEGLU : (p.d.epi_mode == ALDM_EPI_QKV ? OS_EPI_QKV : OS_EPI_PLAIN);
+#define ALDM_OS_E(KT_, NST_, NP_, E_)                                                                            \
+    hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_, E_>), grid, dim3(512), 0, st, p)
 #define ALDM_OS(KT_, NST_, NP_)                                                                                  \
     if (KT == KT_ && nst == NST_ && parts == NP_) {                                                              \
-        hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_>), grid, dim3(512), 0, st, p);                   \
+        if (epi == OS_EPI_GEGLU) ALDM_OS_E(KT_, NST_, NP_, OS_EPI_GEGLU);                                        \
+        else if (epi == OS_EPI_QKV) ALDM_OS_E(KT_, NST_, NP_, OS_EPI_QKV);                                       \
+        else ALDM_OS_E(KT_, NST_, NP_, OS_EPI_PLAIN);                                                            \
         return 0;                                                                                                \
     }
     ALDM_OS(8, 2, 3)
@@ -32,6 +38,7 @@ int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, c
     ALDM_OS(12, 2, 2)
     ALDM_OS(12, 3, 2)
 #undef ALDM_OS
+#undef ALDM_OS_E
     return -1;
 }
 

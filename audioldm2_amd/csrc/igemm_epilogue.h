@@ -95,6 +95,18 @@ __device__ __forceinline__ void split_store4(void* img, int64_t row, int Cs, int
         if (q < parts) *reinterpret_cast<u32x2*>(base + q * 64) = part[q];
 }
 
+// ... with the image format known at compile time: no `q < parts` branches around the stores, one split form compiled
+template <int P>
+__device__ __forceinline__ void split_store4_t(void* img, int64_t row, int Cs, int c, const f32x4 v) {
+    static_assert(P == 2 || P == 3, "2 or 3 parts");
+    u32x2 part[3];
+    if constexpr (P == 2) split4_rn2(v, part);
+    else split4(v, part);
+    char* base = reinterpret_cast<char*>(img) + (row * (Cs >> 5) + (c >> 5)) * (64 * P) + (c & 31) * 2;
+#pragma unroll
+    for (int q = 0; q < P; ++q) *reinterpret_cast<u32x2*>(base + q * 64) = part[q];
+}
+
 // one output element through the fused epilogue (split-K reduce and ragged-N fallbacks)
 __device__ __forceinline__ float epi_value(const aldm_igemm_desc& d, int rb_ld, const float* __restrict__ outp,
                                            const float* __restrict__ resp, int b, int64_t o, int n, float v) {
