@@ -449,6 +449,11 @@ class LatentDiffusion(nn.Module):
         B = x.shape[0]
         if os.environ.get("ALDM_CFG_STREAMS", "0") == "1" and x.shape[0] * 2 == t2.shape[0]:
             return self._apply_model_cfg_two_streams(x, t2, prepared)
+        if x.shape[0] * 2 == t2.shape[0] and os.environ.get("ALDM_CFG_SHARE", "1") != "0":
+            # both halves see this x and the same t (t2 = t.repeat(2), ddim.py:293-296): the UNet runs its context-free prefix once
+            eps = self.model.diffusion_model(x.contiguous(), t2, context_list=prepared["ctxs"], y=prepared["y"],
+                                             context_attn_mask_list=prepared["masks"], cfg_shared=True)
+            return eps.view(2, B, *eps.shape[1:])
         x2 = x.repeat(2, 1, 1, 1) if x.shape[0] * 2 == t2.shape[0] else x
         eps = self.model.diffusion_model(x2.contiguous(), t2, context_list=prepared["ctxs"], y=prepared["y"],
                                          context_attn_mask_list=prepared["masks"])

@@ -299,12 +299,14 @@ class TimestepEmbedSequential(nn.Sequential):
     """openaimodel.py:75-103: routes emb to ResBlocks and (context, mask) to SpatialTransformers; the
     first transformer of a block never gets a context, transformers beyond the list get None."""
 
-    def run(self, x, emb, context_list, mask_list, x2=None):
-        """emb: dict-like indexable by a ResBlock's `_emb_slice` -> [B, out_channels] row-bias view."""
+    def run(self, x, emb, context_list, mask_list, x2=None, lo=0, hi=None):
+        """emb: dict-like indexable by a ResBlock's `_emb_slice` -> [B, out_channels] row-bias view.  lo / hi: run layers
+        [lo, hi) only (UNetModel's shared classifier-free-guidance prefix stops inside a block)."""
         ctxs = [None] + list(context_list)
         masks = [None] + list(mask_list)
-        st_id = 0
-        for layer in self:
+        layers = list(self)
+        st_id = sum(isinstance(l, SpatialTransformer) for l in layers[:lo])
+        for layer in layers[lo:hi]:
             if isinstance(layer, ResBlock):
                 x = layer.run(x, emb[layer._emb_slice], x2)
                 x2 = None
@@ -503,8 +505,25 @@ class UNetModel(nn.Module):
 
     # -- forward -----------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, timesteps=None, y=None, context_list=None, context_attn_mask_list=None, **kwargs):
-        """openaimodel.py:837-885.  x: [N, C, H, W] fp32 on the GPU; returns eps [N, C_out, H, W]."""
+    def _shared_prefix_end(self, context_list):
+        """(input block, layer) of the first SpatialTransformer that receives a context — where the two halves of a
+        classifier-free-guidance batch start to differ (TimestepEmbedSequential: the first transformer of a block never gets a
+        context, transformer k > 0 gets context_list[k - 1]); None when the halves differ from the start (FiLM: `y` enters every
+        ResBlock) or no transformer ever gets a context."""
+        if self.use_extra_film_by_concat:
+            return None
+        for bi, blk in enumerate(self.input_blocks):
+            st = 0
+            for li, layer in enumerate(blk):
+                if isinstance(layer, SpatialTransformer):
+                    if st >= 1 and st - 1 < len(context_list) and context_list[st - 1] is not None:
+                        return bi, li
+                    st += 1
+        return None
+
+    def forward(self, x, timesteps=None, y=None, context_list=None, context_attn_mask_list=None, cfg_shared=False, **kwargs):
+        """openaimodel.py:837-885.  x: [N, C, H, W] fp32 on the GPU; returns eps [N, C_out, H, W] (cfg_shared: x [B, ...] once for
+        the 2B rows [uncond ; cond] of a classifier-free-guidance pass, returns eps [2B, ...]; see below)."""
         assert (y is not None) == self.use_extra_film_by_concat, \
             "must specify y if and only if the model is class-conditional or film embedding conditional"
         if not x.is_cuda:
@@ -512,19 +531,51 @@ class UNetModel(nn.Module):
         pk = self._prepare()
         context_list = [c.float().contiguous() if c is not None else None for c in (context_list or [])]
         mask_list = list(context_attn_mask_list or [])
+        # Shared classifier-free-guidance prefix (round 5).  With cfg_shared=True the caller passes x ONCE ([B, ...]) for a batch
+        # whose rows [0, B) (unconditional) and [B, 2B) (conditional) see the same x and the same t and differ only in their
+        # contexts (ddim.py:293-296 runs them as two passes over the same x).  Until the first SpatialTransformer that RECEIVES a
+        # context the two halves compute identical values — conv_in, the level-0 ResBlocks, the first Downsample, the first
+        # level-1 ResBlock, the context-free first transformer — so that prefix runs on B samples and its output (and its skip
+        # tensors, when the decoder pops them) is duplicated: 4 of 7 level-0 convs at half the rows, ~0.5 ms of a 22 ms step.
+        div = self._shared_prefix_end(context_list) if cfg_shared else None
+        B = x.shape[0]
+        if cfg_shared:
+            assert timesteps.shape[0] in (B, 2 * B) and all(c is None or c.shape[0] == 2 * B for c in context_list), \
+                "cfg_shared: x [B, ...] once, contexts for the 2B rows [uncond ; cond]"
+            timesteps = timesteps[:B]
+            if div is None:   # FiLM-conditioned model (y differs between the halves from the first ResBlock on): nothing to share
+                x = x.repeat(2, 1, 1, 1)
+                timesteps = timesteps.repeat(2)
         t_emb = ops.timestep_embedding(timesteps, self.model_channels)
         emb = ops.linear(ops.linear(t_emb, pk["te0"], act=ACT_SILU), pk["te2"])
         if self.use_extra_film_by_concat:
             emb = torch.cat([emb, ops.linear(y.float().contiguous(), pk["film"])], dim=-1).contiguous()
-        emb = _EmbSlices(ops.linear(emb, pk["emb_all"], pre_act=ACT_SILU))
+        emb_rows = ops.linear(emb, pk["emb_all"], pre_act=ACT_SILU)
+        emb = _EmbSlices(emb_rows)
         h = ops.nchw_to_nhwc(x.float().contiguous())
         hs = []
-        for module in self.input_blocks:
-            h = module.run(h, emb, context_list, mask_list)
-            hs.append(h)
+        if div is None:
+            for module in self.input_blocks:
+                h = module.run(h, emb, context_list, mask_list)
+                hs.append(h)
+        else:
+            dup = lambda t: t.repeat(2, *([1] * (t.dim() - 1)))   # rows [B, 2B) = rows [0, B)
+            emb_half, emb = emb, _EmbSlices(dup(emb_rows))
+            for bi, module in enumerate(self.input_blocks):
+                if bi < div[0]:
+                    h = module.run(h, emb_half, context_list, mask_list)
+                elif bi == div[0]:
+                    h = module.run(h, emb_half, context_list, mask_list, hi=div[1])
+                    h = module.run(dup(h), emb, context_list, mask_list, lo=div[1])
+                else:
+                    h = module.run(h, emb, context_list, mask_list)
+                hs.append(h)
         h = self.middle_block.run(h, emb, context_list, mask_list)
         for module in self.output_blocks:
-            h = module.run(h, emb, context_list, mask_list, x2=hs.pop())
+            skip = hs.pop()
+            if skip.shape[0] != h.shape[0]:   # a skip tensor of the shared prefix
+                skip = dup(skip)
+            h = module.run(h, emb, context_list, mask_list, x2=skip)
         sc, sh = ops.gn_stats(h, *pk["gn"], groups=32, eps=1e-5)
         out = ops.conv(h, pk["out"], pad=(1, 1), pre=(sc, sh), pre_act=ACT_SILU)
         return ops.nhwc_to_nchw(out)

@@ -728,3 +728,20 @@ def test_parity_on_checkpoint_script_reference_stage_and_checkpoint_loading(tmp_
         r = subprocess.run([sys.executable, script, "--ckpt", str(ckpt), "--stage", "hip", "--cache", str(cache), "--steps", "1",
                             "--batch", "1"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 2 and "needs the MI355X" in r.stderr
+
+
+def test_shared_cfg_prefix_ends_at_the_first_transformer_with_a_context():
+    """UNetModel._shared_prefix_end: the two halves of a classifier-free-guidance batch compute the same values until the first
+    SpatialTransformer that receives a context (input block 4, layer 2 in every cross-attention config: ResBlock, context-free
+    transformer | AudioMAE transformer ...); the FiLM-conditioned 48 kHz model shares nothing (y enters every ResBlock)."""
+    from audioldm2_amd.pipeline import build_model
+    from audioldm2_amd.unet import ResBlock, SpatialTransformer
+    for name, nctx in (("audioldm2-full", 2), ("audioldm2-full-large-1150k", 2), ("audioldm2-speech-gigaspeech", 1)):
+        u = build_model(model_name=name).model.diffusion_model
+        bi, li = u._shared_prefix_end([torch.zeros(1)] * nctx)
+        assert (bi, li) == (4, 2)
+        blk = list(u.input_blocks[bi])
+        assert isinstance(blk[0], ResBlock) and isinstance(blk[1], SpatialTransformer) and isinstance(blk[2], SpatialTransformer)
+        assert not any(isinstance(l, SpatialTransformer) for b in list(u.input_blocks)[:bi] for l in b)
+        assert u._shared_prefix_end([]) is None and u._shared_prefix_end([None, None]) is None
+    assert build_model(model_name="audioldm_48k").model.diffusion_model._shared_prefix_end([]) is None

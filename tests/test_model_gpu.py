@@ -459,6 +459,30 @@ def test_cfg_batched_equals_two_passes_and_graph_equals_eager(ld):
     assert torch.equal(eager["latent"], graph["latent"])
 
 
+def test_shared_cfg_prefix_equals_the_full_two_half_pass(ld):
+    """Round 5: apply_model_cfg hands the UNet x ONCE and the UNet runs everything in front of the first transformer that receives
+    a context — identical for the unconditional and the conditional half — on B samples instead of 2B (UNetModel.forward,
+    cfg_shared).  Same values as the pass over the repeated batch (ALDM_CFG_SHARE=0) up to the summation orders the two batch
+    sizes' tiles pick; per-sample timesteps and the padded / masked contexts included."""
+    B = 3
+    batch = cases.e2e_batch(B)
+    cond = ld.get_learned_conditioning_dict(batch)
+    uncond = {k: ld.cond_stage_models[m["model_idx"]].get_unconditional_condition(B)
+              for k, m in ld.cond_stage_model_metadata.items()}
+    assert ld.model.diffusion_model._shared_prefix_end([torch.zeros(1)] * 2) == (4, 2)
+    x = cases.latent_input(B, 8, 256, 16, seed=21).cuda()
+    t2 = torch.tensor([801.0, 401.0, 1.0]).repeat(2).cuda()
+    shared = ld.apply_model_cfg(x, t2, cond, uncond)
+    os.environ["ALDM_CFG_SHARE"] = "0"
+    try:
+        full = ld.apply_model_cfg(x, t2, cond, uncond)
+    finally:
+        os.environ.pop("ALDM_CFG_SHARE")
+    assert shared.shape == full.shape == (2, B, 8, 256, 16)
+    assert rel(shared, full) < batch_tol()
+    assert rel(shared[0], shared[1]) > 1e-3   # the halves do differ (their contexts do)
+
+
 def test_callback_draws_are_sequenced_with_the_step_noise_like_the_reference(ld):
     """in the reference any callback may draw from torch's default generator between two steps (ddim.py:246-249 call it
     right after p_sample_ddim's `torch.randn`, ddim.py:351).  A run that is GIVEN a callback therefore keeps the draws on the
