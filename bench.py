@@ -17,7 +17,7 @@ MFMA partial products of exact 3-part operand splits — fp32-grade (2.4e-7 rms 
 not narrower than the reference's fp32 multiply.  Prints ONE JSON line on rank 0 with the contract keys plus
   `roofline`      dominant igemm instantiation + the attention kernel, measured live with events on the launch stream (the cost of
                   an empty event pair, measured in the same run, is subtracted so the durations compare with rocprofv3's), HBM
-                  traffic from profiles/r04_pmc_traffic_<mode>.json while its source hash matches the running kernels;
+                  traffic from profiles/r05_pmc_traffic_<mode>.json while its source hash matches the running kernels;
   `roofline_tail` VAE decode and HiFi-GAN;
   `fast`          the same job re-run in the opt-in "bf16x3" mode (16-bit operand significands: NARROWER than fp32 — a named
                   sub-record, never the headline);
@@ -53,7 +53,7 @@ PEAK_BF16X6_TFLOPS = round(2500.0 / 6.0, 1)
 PEAK_BF16X3_TFLOPS = round(2500.0 / 3.0, 1)
 def traffic_json(mode):
     """PMC traffic file of the product mode (tools/pmc_traffic.py, stamped with the kernel-source hash)."""
-    return os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{mode}.json")
+    return os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{mode}.json")
 MODE_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}
 MODE_DTYPE = {
     "f32": "f32 (storage, accumulate and products: fp32 MFMA)",
