@@ -17,9 +17,7 @@ bool igemm_dma_lw_config_ok(int BM, int BN, int nst, int parts) {
     }
     if (BM == 128 && BN == 128) return nst == 2 || nst == 3;
     if ((BM == 64 && BN == 128) || (BM == 128 && BN == 64)) return nst == 2 || nst == 4;
-    // (round 5: 4- and 6-deep rings of the 64x64 tile on 3-part images — 96 / 144 KB: one block per CU, which is all a 1024-row
-    //  launch has anyway: its 20 k-tiles are paced by the L2 -> LDS round trip divided by the tiles in flight)
-    if (BM == 64 && BN == 64) return nst == 2 || nst == 3 || nst == 4 || nst == 6;
+    if (BM == 64 && BN == 64) return nst == 2 || nst == 3;
     return false;
 }
 
@@ -59,8 +57,6 @@ int igemm_launch_dma_lw(int BM, int BN, int nst, int parts, dim3 grid, hipStream
     ALDM_LW(128, 64, 4, 2, 3)
     ALDM_LW(64, 64, 2, 2, 3)
     ALDM_LW(64, 64, 3, 2, 3)
-    ALDM_LW(64, 64, 4, 2, 3)
-    ALDM_LW(64, 64, 6, 2, 3)
 #undef ALDM_LW
     (void)lw_bpc;
     return -1;
