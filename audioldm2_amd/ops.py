@@ -334,8 +334,9 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
     if d.a_split:
         nst = _l.load().aldm_igemm_plan_stages(C.byref(d))
-        if nst >= 300:   # operand-stationary kernel for short K (csrc/igemm_dma_os.h): <k-tiles, ring depth, parts>
-            return f"igemm_dma_os_kernel<{d.K // 32}, {nst - 300}, {d.split_parts or 3}>"
+        if nst >= 300:   # operand-stationary kernel for short K (csrc/igemm_dma_os.h): <k-tiles, ring depth, parts, epilogue form>
+            epi = 1 if d.epi_mode == _l.EPI_GEGLU else (2 if d.epi_mode == _l.EPI_QKV else 0)   # OS_EPI_GEGLU / _QKV / _PLAIN
+            return f"igemm_dma_os_kernel<{d.K // 32}, {nst - 300}, {d.split_parts or 3}, {epi}>"
         if nst >= 200:   # loader waves (csrc/igemm_dma_lw.h; rocprofv3 appends the blocks-per-CU template argument)
             return f"igemm_dma_lw_kernel<{bm}, {bn}, {nst - 200}, {4 if bm == 256 else 2}, {d.split_parts or 3}>"
         if nst >= 100:   # the persistent wave-specialised form (csrc/igemm_dma_ws.h)

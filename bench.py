@@ -339,7 +339,11 @@ def roofline_probe(ld, batch, B):
         from audioldm2_amd.lib import source_hash
         with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
-        ent = tj.get("kernels", {}).get(kname)
+        # rocprofv3 spells trailing template arguments the Python-side name does not carry (igemm_dma_kernel's DROP = false, the
+        # loader-wave kernel's blocks per CU): exact name, else the one entry the name is a prefix of
+        ks = tj.get("kernels", {})
+        cands = [k for k in ks if k == kname or k.startswith(kname[:-1] + ", ")]
+        ent = ks[cands[0]] if len(cands) == 1 else None
         if tj.get("source_hash") != source_hash():
             # the PMC passes were collected on other kernel sources than the ones running now: not evidence for this line
             traffic_src = {"file": "profiles/" + os.path.basename(TRAFFIC_JSON), "stale": True,

@@ -2,7 +2,7 @@
 prescribes) of the bench command into profiles/rNN_pmc_traffic.json (stamped with audioldm2_amd.lib.source_hash()): average HBM bytes per launch for
 each igemm instantiation (tile x prologue mode, named as rocprofv3 names them).  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of
 the bytes of wide (16 B/lane) coalesced reads (same guide) -> doubled here, raw value kept too.
-Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+Usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [command the passes profiled]"""
 import csv
 import glob
 import json
@@ -34,9 +34,10 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from audioldm2_amd.lib import source_hash
     out = {"source_hash": source_hash(),
-           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) of "
-                     "ALDM_NO_GRAPH=1 python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline",
-           "units": "bytes per launch, averaged over all launches of the instantiation (all prologue modes)",
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) of " +
+                     (sys.argv[4] if len(sys.argv) > 4 else
+                      "ALDM_NO_GRAPH=1 python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline"),
+           "units": "bytes per launch, averaged over all launches of the instantiation in that command (all prologue modes)",
            "kernels": {}}
     for k in sorted(fetch):
         n, tot = fetch[k]
