@@ -27,6 +27,8 @@ not narrower than the reference's fp32 multiply.  Prints ONE JSON line on rank 0
                   tokens, VITS phoneme encoder; random-init weights, stub tokenizers): ms per batch and audio-s/s including them;
   `api_default`   N = 1 only: the public API's default n_candidate_gen_per_text = 3 (pipeline.py:181-193): 3 x the UNet work
                   plus CLAP re-ranking (HTSAT-base + RoBERTa-base), delivered audio-s/s;
+  `replicas_one_gpu`  N = 1 only: TWO jobs of the headline batch in flight on the one GPU (two processes through this script's own
+                  launcher): what a second hardware queue recovers from the latency-bound launches — a named sub-record, 16 prompts resident;
   `cpu_baseline`  the CPU oracle = the reference's arithmetic on the host cores, bounded sample.
 `dtype` and every `*_frac_of_*_peak` name the arithmetic that actually ran.
 """
@@ -118,6 +120,8 @@ def parse():
     ap.add_argument("--fast-steps", type=int, default=1, help="timed jobs of the fast re-run (after one warm-up job)")
     ap.add_argument("--no-conditioners", action="store_true", help="skip the conditioner stacks reported under `conditioners`")
     ap.add_argument("--no-api-default", action="store_true", help="skip the n_candidate_gen_per_text = 3 job (`api_default`)")
+    ap.add_argument("--no-replicas", action="store_true",
+                    help="skip the `replicas_one_gpu` sub-record (two concurrent jobs of the headline batch on the one GPU)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: spawn --gpus ranks (gloo), rendezvous, shard the global batch, print ONE "
                          "JSON line listing every rank; no kernels run")
@@ -753,6 +757,32 @@ def main():
                 out["conditioners"][name] = ent
             except Exception as e:  # pragma: no cover
                 out["conditioners"][name] = {"error": repr(e)}
+    # ---- two JOBS of the headline batch in flight on the ONE GPU (two processes = two hardware queues; round 5: a second queue fills
+    # the idle compute units the first one's latency-bound launches leave: 21.0-21.5 against 18.3-18.4 audio-s/s on one box,
+    # profiles/r05_replicas_one_gpu.txt).  NOT the headline: 2 x B prompts are resident, and a job's latency nearly doubles — it is
+    # what a server that always has a second batch queued gets from the same GPU.  Runs this script as two gloo ranks through its own launcher.
+    if world == 1 and rank == 0 and not args.no_replicas and not args.no_configs and args.model == "audioldm2-full":
+        try:
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            env["ALDM_DIST_BACKEND"] = "gloo"
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", str(B),
+                   "--ddim-steps", str(args.ddim_steps), "--no-cpu-baseline", "--no-roofline", "--no-step-probe", "--no-fast", "--no-configs",
+                   "--no-conditioners", "--no-api-default", "--no-replicas"] + (["--mma", args.mma] if args.mma else [])
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            rec = json.loads(line[-1]) if r.returncode == 0 and line else None
+            if rec is None:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr[-300:]}")
+            out["replicas_one_gpu"] = {
+                "value": rec["value"], "unit": "audio-s/s", "jobs_in_flight": 2, "prompts_resident": 2 * B, "steps": rec["steps"],
+                "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "per_rank_seconds": rec.get("per_rank_seconds"),
+                "vs_headline": round(rec["value"] / value, 4),
+                "note": "NOT the headline: two processes (two hardware queues), each running the headline job on its own 8 prompts on the "
+                        "SAME GPU, launched by bench.py's own launcher with ALDM_DIST_BACKEND=gloo; 16 prompts resident, per-job latency "
+                        "= ms_per_step"}
+        except Exception as e:  # pragma: no cover
+            out["replicas_one_gpu"] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             try:
