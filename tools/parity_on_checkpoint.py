@@ -72,6 +72,22 @@ def load_state_dict_file(path):
     return sd
 
 
+def make_random_checkpoint(path, model):
+    """A random-init checkpoint in the reference's format WITHOUT the reference: this repository's module tree carries the reference's
+    state-dict keys and shapes (tests/test_host_logic.py pins them to the real classes), so its state dict with deterministic hot-path
+    tensors (oracle/weights.py, the generator behind every fixture) is a file both stages load.  For exercising the two stages on machines
+    that have no released checkpoint (the CPU suite; tools/gpu/r5_run9.sh runs the hip stage on it)."""
+    from audioldm2_amd.pipeline import build_model
+    from oracle import cases, weights
+    sd = build_model(model_name=model).state_dict()
+    hot = {k: tuple(v.shape) for k, v in sd.items() if k.startswith(HOT_PREFIXES)}
+    sd.update(weights.make_state_dict(hot, seed=3))
+    sd["scale_factor"] = torch.tensor(cases.SCALE_FACTOR)
+    sd = {k: v for k, v in sd.items() if not k.startswith(("cond_stage_models.", "clap."))}
+    torch.save({"state_dict": sd, "note": "random-init (oracle.weights seed 3), reference key layout"}, path)
+    print(f"wrote {path}: {len(sd)} tensors ({len(hot)} hot-path)", flush=True)
+
+
 def reference_stage(args, jobs):
     """The real reference on the CPU."""
     if args.reference_root:
@@ -189,7 +205,11 @@ def main():
     ap.add_argument("--cache", default="parity_reference.npz", help="reference outputs (written by the reference stage, read by the hip stage)")
     ap.add_argument("--mma", choices=["bf16x6", "bf16x3", "f32"], default=None)
     ap.add_argument("--threads", type=int, default=0, help="CPU threads of the reference stage (0: torch default)")
+    ap.add_argument("--make-random-ckpt", action="store_true",
+                    help="first write --ckpt as a deterministic random-init checkpoint in the reference's key layout (no released checkpoint at hand)")
     args = ap.parse_args()
+    if args.make_random_ckpt:
+        make_random_checkpoint(args.ckpt, args.model)
     steps = [int(s) for s in args.steps.split(",")]
     bs = [int(b) for b in args.batch.split(",")]
     bs = bs * len(steps) if len(bs) == 1 else bs
