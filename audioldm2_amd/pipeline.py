@@ -293,6 +293,9 @@ class LatentDiffusion(nn.Module):
         # ddpm.py:114-120: the CLAP re-ranker of n_candidate_gen_per_text > 1 (checkpoint keys `clap.model.*`).
         # build_clap=False (the synthetic-conditioner configs of default_audioldm_config) leaves it out; `clap_config`
         # passes geometry overrides (tests).
+        # ddpm.py:679, 852-855, 916-917: get_input draws one torch.rand(1) (make_decision(unconditional_prob_cfg)) on every call
+        # EXCEPT the first of this object's life — part of the RNG contract (see _cfg_dropout_draw)
+        self.conditional_dry_run_finished = False
         self.clap = None
         if build_clap:
             from .clap import CLAPAudioEmbeddingClassifierFreev2
@@ -673,6 +676,18 @@ class LatentDiffusion(nn.Module):
             self._warned_clap_random = True
 
     @torch.no_grad()
+    def _cfg_dropout_draw(self):
+        """RNG contract R, the draw nobody asked for: `LatentDiffusion.get_input` (ddpm.py:850-855) asks
+        `make_decision(unconditional_prob_cfg)` = `float(torch.rand(1)) < p` whether to drop the conditioning — but only `if
+        self.conditional_dry_run_finished`, a flag that is False when the object is built (ddpm.py:679) and set at the end of the first
+        `get_input` (ddpm.py:916-917).  `generate_batch` / `generate_batch_masked` pass p = 0.0, so the answer is always "no"; the DRAW
+        still happens, between the posterior sample and the conditioners, on every call except an object's first — and shifts every later
+        random number of the job.  A process that calls `text_to_audio` twice with the same seed therefore gets two different clips from
+        the reference (found in round 5 by tools/parity_on_checkpoint.py running two jobs in one process); so does this class."""
+        if self.conditional_dry_run_finished:
+            torch.rand(1)
+        self.conditional_dry_run_finished = True
+
     def generate_batch(self, batch, ddim_steps=200, ddim_eta=1.0, x_T=None, n_gen=1,
                        unconditional_guidance_scale=1.0, unconditional_conditioning=None, use_plms=False,
                        **kwargs):
@@ -687,6 +702,7 @@ class LatentDiffusion(nn.Module):
         B0 = fb.shape[0]
         f = 2 ** (self.first_stage_model.encoder.num_resolutions - 1)
         torch.randn((B0, self.first_stage_model.embed_dim, fb.shape[-2] // f, fb.shape[-1] // f))  # (R1) draw & discard
+        self._cfg_dropout_draw()                                                                     # (R1b) every call but the first
         c = self.get_learned_conditioning_dict(batch)
         batch_size = B0 * n_gen
         for k in c.keys():
@@ -767,6 +783,7 @@ class LatentDiffusion(nn.Module):
         fb = batch["log_mel_spec"] if self.first_stage_key == "fbank" else batch[self.first_stage_key]
         x = fb.unsqueeze(1).float().contiguous().to(self.device)  # DDPM.get_input: [B, 1, T, F]
         z = self.get_first_stage_encoding(self.encode_first_stage(x))  # (R1) posterior draw, really used here
+        self._cfg_dropout_draw()                                        # (R1b) every call but the first
         c = self.get_learned_conditioning_dict(batch)
         B0 = z.shape[0]
         batch_size = B0 * n_gen

@@ -74,6 +74,14 @@ class OracleLatentDiffusion:
         self.cond_models = {k: instantiate_from_config(v) for k, v in cond_cfg.items()}
         self.cond_stage_key = {k: v["cond_stage_key"] for k, v in cond_cfg.items()}
         self.channels, self.latent_t_size, self.latent_f_size = 8, 256, 16
+        self.conditional_dry_run_finished = False   # ddpm.py:679
+
+    def _cfg_dropout_draw(self):
+        """ddpm.py:850-855, 916-917: `get_input` draws `torch.rand(1)` (make_decision(unconditional_prob_cfg), always "no" at p = 0.0)
+        on every call except the first of the object's life — between the posterior sample and the conditioners."""
+        if self.conditional_dry_run_finished:
+            torch.rand(1)
+        self.conditional_dry_run_finished = True
 
     def apply_model(self, x, t, cond):
         # DiffusionWrapper.forward (ddpm.py:1821-1879): film* keys -> y (squeeze(1), concatenated),
@@ -95,6 +103,7 @@ class OracleLatentDiffusion:
         f = 2 ** (len(self.dd["ch_mult"]) - 1)
         torch.randn((B, self.dd["z_channels"], batch["log_mel_spec"].shape[1] // f,
                      batch["log_mel_spec"].shape[2] // f))  # posterior draw (distributions.py:37-41)
+        self._cfg_dropout_draw()
         cond = {k: m(batch if self.cond_stage_key[k] == "all" else batch[self.cond_stage_key[k]])
                 for k, m in self.cond_models.items()}
         uncond = None
@@ -120,6 +129,7 @@ class OracleLatentDiffusion:
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         z = torch.tensor(self.scale_factor) * (mean + std * torch.randn(mean.shape))
         B, _, h, w = z.shape
+        self._cfg_dropout_draw()
         cond = {k: m(batch if self.cond_stage_key[k] == "all" else batch[self.cond_stage_key[k]])
                 for k, m in self.cond_models.items()}
         mask = torch.ones(B, h, w)

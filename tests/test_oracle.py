@@ -127,6 +127,28 @@ def test_e2e_oracle_matches_reference_generate_batch_5step():
     assert rel(out["wave"], g["wave"]) < 1e-4
 
 
+@pytest.mark.timeout(900)
+def test_oracle_two_jobs_in_one_process_match_the_real_reference_second_call_included():
+    """The draw nobody asked for (ddpm.py:850-855, 916-917): from its SECOND `get_input` on, a reference `LatentDiffusion` draws one
+    `torch.rand(1)` per job (make_decision(unconditional_prob_cfg = 0.0): always "no", but the generator moves), so the same seed gives a
+    different clip on the second call.  `tests/golden/parity_script_ref_s5b2_s20b1.npz` was written by the REAL reference running TWO jobs
+    in one process on the deterministic checkpoint of `tools/parity_on_checkpoint.py --make-random-ckpt` (oracle.weights seed 3): 5 steps x
+    2 prompts (first call), then 20 steps x 1 prompt (second call).  The oracle — and the product, in the GPU suite — must reproduce
+    both; without the second call's extra draw job 2 is a different clip (relative error ~1.4, the bug this test pins)."""
+    from oracle import weights
+    from oracle.pipeline import OracleLatentDiffusion, hot_path_shapes
+    g = gold("parity_script_ref_s5b2_s20b1")
+    o = OracleLatentDiffusion(sd=weights.make_state_dict(hot_path_shapes(), seed=3))
+    torch.manual_seed(cases.E2E_SEED)
+    a = o.generate_batch(cases.e2e_batch(2), unconditional_guidance_scale=3.5, ddim_steps=5)
+    assert rel(a["latent"], g["s5_b2_latent"]) < 1e-4 and rel(a["wave"], g["s5_b2_wave"]) < 1e-4
+    assert o.conditional_dry_run_finished
+    torch.manual_seed(cases.E2E_SEED)
+    b = o.generate_batch(cases.e2e_batch(1), unconditional_guidance_scale=3.5, ddim_steps=20)
+    assert rel(b["latent"], g["s20_b1_latent"]) < 1e-4 and rel(b["mel"], g["s20_b1_mel"]) < 1e-4
+    assert rel(b["wave"], g["s20_b1_wave"]) < 1e-4
+
+
 def test_e2e_oracle_matches_reference_generate_batch_masked():
     """Inpainting / super-resolution path vs the real LatentDiffusion.generate_batch_masked fixture
     (B=1, 4 DDIM steps, CFG 2.5, seed 42): VAE encode + posterior draw, mask, q_sample blend order."""
