@@ -757,10 +757,10 @@ def main():
                 out["conditioners"][name] = ent
             except Exception as e:  # pragma: no cover
                 out["conditioners"][name] = {"error": repr(e)}
-    # ---- two JOBS of the headline batch in flight on the ONE GPU (two processes = two hardware queues; round 5: a second queue fills
-    # the idle compute units the first one's latency-bound launches leave: 21.0-21.5 against 18.3-18.4 audio-s/s on one box,
-    # profiles/r05_replicas_one_gpu.txt).  NOT the headline: 2 x B prompts are resident, and a job's latency nearly doubles — it is
-    # what a server that always has a second batch queued gets from the same GPU.  Runs this script as two gloo ranks through its own launcher.
+    # ---- two JOBS of the headline batch in flight on the ONE GPU (two processes through this script's own launcher; round 5: 21.0-21.5
+    # against 18.3-18.4 audio-s/s on one box, profiles/r05_replicas_one_gpu.txt; ONE 16-prompt job gives the same +16 ... +19 %,
+    # r05_sixteen_prompts_one_gpu.txt: at 8 prompts x CFG = 16 rows per pass the chip is under-filled).  NOT the headline: 2 x B prompts are
+    # resident and a job's latency nearly doubles — it is what a server free to keep 16 prompts on the GPU gets from it.
     if world == 1 and rank == 0 and not args.no_replicas and not args.no_configs and args.model == "audioldm2-full":
         try:
             import subprocess
@@ -778,9 +778,9 @@ def main():
                 "value": rec["value"], "unit": "audio-s/s", "jobs_in_flight": 2, "prompts_resident": 2 * B, "steps": rec["steps"],
                 "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "per_rank_seconds": rec.get("per_rank_seconds"),
                 "vs_headline": round(rec["value"] / value, 4),
-                "note": "NOT the headline: two processes (two hardware queues), each running the headline job on its own 8 prompts on the "
-                        "SAME GPU, launched by bench.py's own launcher with ALDM_DIST_BACKEND=gloo; 16 prompts resident, per-job latency "
-                        "= ms_per_step"}
+                "note": "NOT the headline: two processes, each running the headline job on its own 8 prompts on the SAME GPU, launched by "
+                        "bench.py's own launcher with ALDM_DIST_BACKEND=gloo; 16 prompts resident, per-job latency = ms_per_step; one "
+                        "16-prompt job gives about the same (the chip is under-filled at 16 rows per pass)"}
         except Exception as e:  # pragma: no cover
             out["replicas_one_gpu"] = {"error": repr(e)}
     if rank == 0:
