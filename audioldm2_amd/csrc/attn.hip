@@ -20,6 +20,20 @@
 namespace aldm {
 
 
+// max(x of this lane, x of lane ^ 32): v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32 of its
+// second, so (x, x) comes back as (lower half's x everywhere, upper half's x everywhere).  The two results MUST be copied into
+// scalars before they are bit-cast: __builtin_bit_cast(float, sw[1]) on the vector element reads element 0 on this compiler (hipcc,
+// ROCm 7.2 — the quirk igemm_epilogue.h's split4 notes), and the "row maximum" of the online softmax was then the maximum over the
+// LOWER lane half's 16 keys of each tile only.  Found in round 5 (tools/attn_extreme.py): harmless while every key lies within
+// 2^128 of that maximum, because softmax does not depend on its reference — and non-finite output once a key of the other half
+// lies 128 log2 units (89 nats) above it.
+__device__ __forceinline__ float max_across_halves(float x) {
+    const unsigned a = __builtin_bit_cast(unsigned, x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned lo = sw[0], hi = sw[1];
+    return fmaxf(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
+}
+
 // Exact 3-way split of 8 fp32 values (x = hi + mid + lo, each part the top 16 bits of an fp32) into three bf16x8
 // MFMA operands; element j of an operand is x[j].  Same arithmetic as the igemm engine's A-side split
 // (igemm_kernel.h).
@@ -509,9 +523,7 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
                 float mx = tmax[t];
 #pragma unroll
                 for (int r = 8; r < 16; ++r) mx = fmaxf(mx, sc[t][r]);
-                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx),
-                                                                 __builtin_bit_cast(unsigned, mx), false, false);
-                mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+                mx = max_across_halves(mx);
                 m_new[t] = fmaxf(m_run[t], mx);
                 alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new[t]);   // 0 on the first tile (m_run = -inf)
                 m_run[t] = m_new[t];
@@ -763,9 +775,7 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
             float mx = tmax[t];
 #pragma unroll
             for (int r = 8; r < 16; ++r) mx = fmaxf(mx, S[P][t][r]);
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false,
-                                                             false);
-            mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            mx = max_across_halves(mx);
             m_new[t] = fmaxf(m_run[t], mx);
             alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new[t]);   // 0 on the first tile (m_run = -inf)
             m_run[t] = m_new[t];
@@ -926,6 +936,400 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     }
 }
 
+// ---- round 5 (second step, OPT-IN: ALDM_ATTN_SCHED=2): one pass over the scores — a FIXED softmax reference per query row ----------
+// An experiment, kept for its ablation builds (ALDM_ATTN3_ABLATE, profiles/r05_attn_ablate.txt) — it answered what bounds this loop.
+// attention_d32_presplit2_kernel's loop carries ~316 VALU instructions per key tile beside 48 MFMAs.  A third of them exist only
+// because the row maximum must be known before the first exponential: the running max over all scores, a subtract per score, the
+// alpha bookkeeping and the rescale of O^T, the probabilities written back in place and read again by the operand split.  None of
+// this is needed for the RESULT: softmax is invariant to the reference m in p = 2^(s - m) as long as nothing overflows, and
+// O^T / l is formed once at the end.  This kernel therefore
+//   * takes the row's reference from tile 0 (its exact maximum) and keeps it: -m sits in a 16-register block that is the C operand
+//     of every tile's first Q.K^T MFMA, so the accumulators hold s - m and no subtract is issued;
+//   * reads each score ONCE: exponential, row sum and the 3-part operand split of a PAIR of probabilities are one work item in
+//     three parts of 4 - 6 VALU instructions, one part per MFMA slot (exactly 24 parts per 24-MFMA phase); the P^T operands of
+//     k-step 0 are double-buffered (the previous tile's P.V is reading its own), the scores themselves are never rewritten;
+//   * has no per-tile running max, alpha or O^T rescale.  Instead the tile's row sum is compared with 2^60: only if some row of
+//     the wave collected a probability that large (a score ~40 nats above everything tile 0 held) the wave takes a slow path that
+//     raises those rows' reference to the tile's maximum — rescales O^T and l, recomputes the tile's probabilities from the intact
+//     scores, shifts the next tile's scores — exactly what the online softmax does every tile.  2^60 leaves 2^67 of headroom
+//     to fp32 overflow for the row sum of 1024 keys and for O^T; an overflowed exponential (inf) trips the same test;
+//   * parks the Q^T operands in accumulator registers (MFMAs read them there; the allocator otherwise reloads them 56 times a pair
+//     of tiles) and pins every finished operand dword to its slot (the compiler sinks the splits behind the overflow test otherwise).
+// 226 VALU instructions per key tile (-28 %), 4.7 per MFMA, evenly dealt.  MEASURED (16 x 8 heads x 1024 x 1024, one box): 95.3
+// against 98.7 us (-3.5 %), the UNet step +-0.05 ms — the loop was NOT bound by its VALU instruction count any more.  The ablation
+// builds say by what: MFMAs alone, operands cache-resident, 57 us (the matrix pipe at the power-capped clock); + the real K / V
+// loads 85 us (every wave streams its own copy of K and V^T from L2: 805 MB per launch); + the VALU work 94 - 97 us; the VALU work
+// alone 47 us; four accumulator chains instead of two: slower.  What would move it is K / V shared by a block's four waves through
+// LDS AND less VALU — neither alone (removing either leaves the other: 88 / 87 us).  Error vs fp64 1.2e-6 (exact-max: 7e-7): -m
+// enters the accumulator first, so the 2^-16-sized partial products are rounded at the magnitude of m.  Not the default.
+// Results equal the exact-max kernels' to fp32 rounding (the probabilities differ by one common factor per row that cancels in
+// O^T / l), not bitwise: tests bound the difference to the exact-max path and compare against fp64
+// (test_presplit_kernels_selected_by_env_agree_with_the_default).
+// Work items of tile j: 8 QT pairs; the k-step-0 half runs under the P.V MFMAs of tile j - 1 (phase 2 of iteration j), the
+// k-step-1 half under the Q.K^T MFMAs of tile j + 1 (phase 1 of iteration j + 1); the overflow test sits between the phases.
+#ifndef ALDM_ATTN3_QX_AGPR
+#define ALDM_ATTN3_QX_AGPR 1
+#endif
+#ifndef ALDM_ATTN3_ABLATE
+#define ALDM_ATTN3_ABLATE 0   // timing-only ablation builds (wrong results): 1 every K / V load reads tile 0, 2 no operand splits (parts B, C), 4 no MFMAs in the loop, 8 no exponentials (part A), 16 four MFMA accumulator chains instead of two
+#endif
+template <int QT, int NP>
+__global__ __launch_bounds__(256) void attention_d32_presplit3_kernel(
+    const float* __restrict__ q, const void* __restrict__ k_img, const void* __restrict__ vt_img, float* __restrict__ out,
+    int Lq, int Lk, int ldq, int heads, int ldo, float scale, void* __restrict__ out_split, int split_c, int parts) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
+    if (q0 >= Lq) return;  // wave-uniform
+
+    constexpr int NPROD = NP == 3 ? 6 : 3;
+    constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
+    constexpr int PB_[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
+    constexpr int NMF = NPROD * 2 * QT;   // MFMAs of one product of a tile; MFMA i = (k-step i / (NPROD*QT), product, query tile i % QT)
+
+    // Q^T operands, pre-scaled by scale * log2(e) (scores in log2 units), k-step s covers d = 16*lh + 8*s .. + 7
+    const float qscale = scale * 1.44269504088896340736f;
+    bf16x8 qx[QT][2][3];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = min(q0 + 32 * t + l31, Lq - 1);
+        const float* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32 + 16 * lh;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 8 * s), x1 = *reinterpret_cast<const f32x4*>(qp + 8 * s + 4);
+            float x8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x8[e] = x0[e] * qscale;
+                x8[4 + e] = x1[e] * qscale;
+            }
+            split8_np<NP>(x8, qx[t][s]);
+#if ALDM_ATTN3_QX_AGPR
+            // the Q^T operands are read by MFMAs only, for the whole key loop: park them in accumulator registers (an MFMA reads
+            // its B operand from there directly) instead of letting the allocator spill and reload them around the loop's VALU work
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                u32x4 w = __builtin_bit_cast(u32x4, qx[t][s][pr]);
+                asm volatile("" : "+a"(w));
+                qx[t][s][pr] = __builtin_bit_cast(bf16x8, w);
+            }
+#endif
+        }
+    }
+
+    // the images of this (sample, head): k rows [key][heads][NP][32] bf16, v tiles [tile][NP][32 dims][32 keys] bf16
+    const char* kimg = reinterpret_cast<const char*>(k_img) + ((int64_t)b * Lk * heads + h) * (64 * NP);
+    const char* vimg = reinterpret_cast<const char*>(vt_img) + ((int64_t)b * heads + h) * (Lk >> 5) * (int64_t)(NP * 2048);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(kimg), 0, ((Lk - 1) * heads + 1) * (64 * NP), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(vimg), 0, (Lk >> 5) * NP * 2048, 0x00020000);
+    const int koff = l31 * heads * (64 * NP) + lh * 32;
+    const int voff = l31 * 64 + lh * 16;
+    const int nt = Lk >> 5;
+    const int t_last = nt - 1;    // prefetches past the end re-read the last tile (never used)
+
+    u32x4 Kr[2][2][NP], Vr[2][2][NP];   // [tile parity][k-step][part]: the landing registers ARE the MFMA operands
+    u32x4 px0[2][QT][NP];               // [tile parity]: P^T operands of k-step 0 (written while the previous tile's P.V reads its own)
+    u32x4 px1[QT][NP];                  // ... of k-step 1 (written after the previous tile's P.V has been issued: one set)
+    f32x16 S[2][QT];                    // [tile parity]: scores minus the row's reference (log2 units); written by MFMAs only
+    f32x16 negm[QT];                    // minus the row's reference, in all 16 registers: C of a tile's first Q.K^T MFMA
+    f32x16 oT[QT];
+    float l_run[QT], psum[QT];
+    float cx0 = 0.f, cx1 = 0.f, cr0 = 0.f, cr1 = 0.f;   // the pair in flight between the three parts of a work item
+#if ALDM_ATTN3_ABLATE & 16
+    f32x16 oX[QT], oY[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oX[t][e] = oY[t][e] = 0.f;
+#endif
+    constexpr float BIG = 1152921504606846976.0f;       // 2^60
+
+    auto load_k = [&](auto pc, int tile, int s) {   // k-step s of a K tile
+        constexpr int P = decltype(pc)::value;
+        if (ALDM_ATTN3_ABLATE & 1) tile = 0;
+        const int sk = __builtin_amdgcn_readfirstlane(min(tile, t_last) * 32 * heads * (64 * NP));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Kr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * s + 64 * p, sk, 0);
+    };
+    auto load_v = [&](auto pc, int tile, int s) {
+        constexpr int P = decltype(pc)::value;
+        if (ALDM_ATTN3_ABLATE & 1) tile = 0;
+        const int sv = __builtin_amdgcn_readfirstlane(min(tile, t_last) * (NP * 2048));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) Vr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff + 32 * s + 2048 * p, sv, 0);
+    };
+
+    // One work item = scores 8s + 2p, 8s + 2p + 1 of query tile t -> probabilities, their part of the row sum, dword p of the NP
+    // parts of the tile's P^T operand of k-step s (split8's / split8_rn2's arithmetic), in three parts of 4 - 6 VALU instructions,
+    // one per MFMA slot:  A exponentials + row sum;  B the hi part and the first residuals;  C the mid / lo parts.
+    // The empty asm pins a finished dword to ITS slot: the slow path below rewrites every operand register, which makes these
+    // writes dead on that edge, and the compiler would otherwise sink the splits out of the MFMA phase behind the overflow test.
+    auto px_of = [&](auto pc, int t, int s) -> u32x4(&)[NP] {
+        constexpr int P = decltype(pc)::value;
+        return s == 0 ? px0[P][t] : px1[t];
+    };
+    auto item_a = [&](auto pc, int t, int s, int p) {
+        constexpr int P = decltype(pc)::value;
+        cx0 = __builtin_amdgcn_exp2f(S[P][t][8 * s + 2 * p]);
+        cx1 = __builtin_amdgcn_exp2f(S[P][t][8 * s + 2 * p + 1]);
+        psum[t] = (s == 0 && p == 0) ? cx0 + cx1 : psum[t] + (cx0 + cx1);
+    };
+    auto item_b = [&](auto pc, int t, int s, int p) {
+        u32x4(&dst)[NP] = px_of(pc, t, s);
+        if constexpr (NP == 3) {
+            const unsigned a0 = __builtin_bit_cast(unsigned, cx0), a1 = __builtin_bit_cast(unsigned, cx1);
+            cr0 = cx0 - __builtin_bit_cast(float, a0 & 0xFFFF0000u);
+            cr1 = cx1 - __builtin_bit_cast(float, a1 & 0xFFFF0000u);
+            unsigned d0 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+            asm volatile("" : "+v"(d0));
+            dst[0][p] = d0;
+        } else {
+            using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+            const __bf16 h0 = (__bf16)cx0, h1 = (__bf16)cx1;
+            cr0 = cx0 - (float)h0;
+            cr1 = cx1 - (float)h1;
+            unsigned d0 = __builtin_bit_cast(unsigned, bf16x2{h0, h1});
+            asm volatile("" : "+v"(d0));
+            dst[0][p] = d0;
+        }
+    };
+    auto item_c = [&](auto pc, int t, int s, int p) {
+        u32x4(&dst)[NP] = px_of(pc, t, s);
+        if constexpr (NP == 3) {
+            const unsigned b0 = __builtin_bit_cast(unsigned, cr0), b1 = __builtin_bit_cast(unsigned, cr1);
+            const float s0 = cr0 - __builtin_bit_cast(float, b0 & 0xFFFF0000u), s1 = cr1 - __builtin_bit_cast(float, b1 & 0xFFFF0000u);
+            unsigned d1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+            unsigned d2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+            asm volatile("" : "+v"(d1), "+v"(d2));
+            dst[1][p] = d1;
+            dst[2][p] = d2;
+        } else {
+            using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+            unsigned d1 = __builtin_bit_cast(unsigned, bf16x2{(__bf16)cr0, (__bf16)cr1});
+            asm volatile("" : "+v"(d1));
+            dst[1][p] = d1;
+        }
+    };
+    // part u = 0 .. 12 QT - 1 of the 4 QT items of k-step s of a tile: item u / 3 (query tiles alternate: their row sums are
+    // independent chains; pair p = item / QT), part u % 3
+    constexpr int NU = 12 * QT;
+    auto run_part = [&](auto pc, int s, auto uc, auto loopc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int abl = decltype(loopc)::value ? ALDM_ATTN3_ABLATE : 0;   // (ablation builds strip the key LOOP only)
+        constexpr int k = u / 3, t = k % QT, p = k / QT;
+        if constexpr (u % 3 == 0) {
+            if constexpr (!(abl & 8)) item_a(pc, t, s, p);
+        } else if constexpr (!(abl & 2)) {
+            if constexpr (u % 3 == 1) item_b(pc, t, s, p);
+            else item_c(pc, t, s, p);
+        }
+    };
+    // the slow path: raise the reference of the rows of tile parity P to the tile's maximum where that is above it
+    auto raise_reference = [&](auto pc, auto nextc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr bool NEXT = decltype(nextc)::value;   // the other parity already holds the NEXT tile's scores
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = S[P][t][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[P][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float d = fmaxf(mx, 0.f);              // rows that did not overflow keep their reference (d = 0: no change)
+            const float a = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oT[t][e] *= a;
+            l_run[t] *= a;
+            float ps = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    cx0 = __builtin_amdgcn_exp2f(S[P][t][8 * s + 2 * p] - d);
+                    cx1 = __builtin_amdgcn_exp2f(S[P][t][8 * s + 2 * p + 1] - d);
+                    ps += cx0 + cx1;
+                    item_b(pc, t, s, p);
+                    item_c(pc, t, s, p);
+                }
+            psum[t] = ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[t][r] -= d;
+            if constexpr (NEXT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[1 - P][t][r] -= d;
+            }
+        }
+    };
+    // after the last part of a tile (parity P): the overflow test, then the row sum joins l
+    auto close_tile = [&](auto pc, auto nextc) {
+        bool big = false;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) big |= psum[t] > BIG;
+        if (__builtin_amdgcn_ballot_w64(big) != 0) raise_reference(pc, nextc);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) l_run[t] += psum[t];
+    };
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mfma_qk = [&](auto pc, auto ic, auto firstc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int i = decltype(ic)::value;
+        constexpr bool FIRST = decltype(firstc)::value;   // tile 0: no reference yet
+        constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
+#if ALDM_ATTN3_ABLATE & 16
+        // (timing only: four independent accumulator chains instead of two — is the loop bound by the dependent-MFMA latency?)
+        if constexpr (!FIRST && ((i / QT) & 1)) {
+            oX[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Kr[P][s][PA_[pr]]), qx[t][s][PB_[pr]], oX[t], 0, 0, 0);
+            return;
+        }
+#endif
+        S[P][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Kr[P][s][PA_[pr]]), qx[t][s][PB_[pr]],
+                                                          (s == 0 && pr == 0) ? (FIRST ? zero16 : negm[t]) : S[P][t], 0, 0, 0);
+    };
+    auto mfma_pv = [&](auto vc, auto ic) {   // vc: parity of the V tile (= of the P tile)
+        constexpr int P = decltype(vc)::value;
+        constexpr int i = decltype(ic)::value;
+        constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
+#if ALDM_ATTN3_ABLATE & 16
+        if constexpr ((i / QT) & 1) {
+            oY[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, Vr[P][s][PA_[pr]]),
+                __builtin_bit_cast(bf16x8, s == 0 ? px0[P][t][PB_[pr]] : px1[t][PB_[pr]]), oY[t], 0, 0, 0);
+            return;
+        }
+#endif
+        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8, Vr[P][s][PA_[pr]]),
+            __builtin_bit_cast(bf16x8, s == 0 ? px0[P][t][PB_[pr]] : px1[t][PB_[pr]]), oT[t], 0, 0, 0);
+    };
+
+    // Iteration j (tile parity P, Q = the other one):
+    //   phase 1, NMF slots: Q.K^T of tile j -> S[P];  the k-step-1 parts of tile j - 1 (-> px1; P.V of tile j - 2 has been issued);
+    //                        V^T of tile j in slots 0 and 1
+    //   the overflow test of tile j - 1
+    //   phase 2, NMF slots: P.V of tile j - 1 (px0[Q], px1);  the k-step-0 parts of tile j (-> px0[P]);  K of tile j + 2 in slots
+    //                        0 and 1 (Kr[P] is free: every Q.K^T MFMA of tile j has been issued and has read it)
+    // NU parts over NMF slots: one part per slot in the 3-part form (24 / 24), two in the 2-part form.
+    auto phase_parts = [&](auto pc, int s, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, NU>([&](auto uc) {
+            if constexpr (item_slot<NU, NMF>(decltype(uc)::value, 0) == i) run_part(pc, s, uc, std::true_type{});
+        });
+    };
+    auto body = [&](auto pc, int j) {
+        constexpr int P = decltype(pc)::value, Q = 1 - P;
+        using QC = std::integral_constant<int, Q>;
+        constexpr bool MFMA = !(ALDM_ATTN3_ABLATE & 4);
+#if (ALDM_ATTN3_ABLATE & 4) && defined(__HIP_DEVICE_COMPILE__)
+        // keep the ablated loop a loop: what the removed MFMAs would have produced is opaque to the optimiser
+#pragma unroll
+        for (int t = 0; t < QT; ++t) asm volatile("" : "+v"(S[P][t]), "+v"(oT[t]));
+#endif
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (MFMA) mfma_qk(pc, ic, std::false_type{});
+            phase_parts(QC{}, 1, ic);
+            if constexpr (i < 2) load_v(pc, j, i);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#if (ALDM_ATTN3_ABLATE & 10) == 10
+        // (no work item reads the scores: keep their MFMAs alive)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) asm volatile("" ::"v"(S[P][t]));
+#endif
+#else
+        close_tile(QC{}, std::true_type{});
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (MFMA) mfma_pv(QC{}, ic);
+            phase_parts(pc, 0, ic);
+            if constexpr (i < 2) load_k(pc, j + 2, i);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // prologue: tile 0 (parity 0) — its exact row maximum becomes the reference; nothing to overlap with yet
+    load_k(P0{}, 0, 0);
+    load_k(P0{}, 0, 1);
+    load_k(P1{}, 1, 0);
+    load_k(P1{}, 1, 1);
+    load_v(P0{}, 0, 0);
+    load_v(P0{}, 0, 1);
+    static_for<0, NMF>([&](auto ic) { mfma_qk(P0{}, ic, std::true_type{}); });
+    __builtin_amdgcn_sched_barrier(0);
+    load_k(P0{}, 2, 0);
+    load_k(P0{}, 2, 1);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float mx = S[0][t][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[0][t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[0][t][r] -= mx;
+            negm[t][r] = -mx;
+            oT[t][r] = 0.f;
+        }
+        l_run[t] = 0.f;
+    }
+    static_for<0, NU>([&](auto uc) { run_part(P0{}, 0, uc, std::false_type{}); });
+    __builtin_amdgcn_sched_barrier(0);
+
+    int j = 1;
+    for (; j + 1 < nt; j += 2) {
+        body(P1{}, j);
+        body(P0{}, j + 1);
+    }
+    // the last tile: its k-step-1 parts, the overflow test, P.V — un-overlapped
+    auto tail = [&](auto pc) {   // pc: parity of the LAST tile
+        static_for<0, NU>([&](auto uc) { run_part(pc, 1, uc, std::false_type{}); });
+        close_tile(pc, std::false_type{});
+        static_for<0, NMF>([&](auto ic) { mfma_pv(pc, ic); });
+    };
+    if (j < nt) {   // odd tile left (parity 1)
+        body(P1{}, j);
+        tail(P1{});
+    } else {
+        tail(P0{});
+    }
+
+#if ALDM_ATTN3_ABLATE & 16
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[t][e] += oX[t][e] + oY[t][e];
+#endif
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + 32 * t + l31;
+        if (qi < Lq) {
+            float* op = out ? out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
+                if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
+                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
+            }
+        }
+    }
+}
+
+
 }  // namespace aldm
 
 using namespace aldm;
@@ -1048,25 +1452,35 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
     const float* kf = reinterpret_cast<const float*>(k_split);
     const float* vf = reinterpret_cast<const float*>(vt_split);
     const int split_c = heads * 32;
-    // the re-scheduled loop (attention_d32_presplit2_kernel, same arithmetic and results): ALDM_ATTN_SCHED=0 keeps the round-3 / 4
-    // pipelined kernel for A/Bs (tools/attn_probe.py)
-    static const bool sched2 = [] {
+    // ALDM_ATTN_SCHED (read once; A/Bs with tools/attn_probe.py): unset / 1 = the re-scheduled exact-max loop
+    // (attention_d32_presplit2_kernel; bitwise the fp32-K/V path), 0 = the round-3 / 4 pipelined kernel (bitwise too), 2 = the
+    // one-pass fixed-reference loop (attention_d32_presplit3_kernel: -26 % VALU instructions for -3 % time and 1.7x the error —
+    // the experiment that showed what bounds this loop; kept opt-in for its ablation builds)
+    static const int sched = [] {
         const char* e = getenv("ALDM_ATTN_SCHED");
-        return e == nullptr || e[0] != '0';
+        return e == nullptr ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1));
     }();
 #define ALDM_ATTN_PRE(Q_, P_)                                                                                          \
     hipLaunchKernelGGL((attention_d32_pipe_kernel<false, Q_, P_, true>), grid, dim3(256), 0, st, q, kf, vf, out, Lq, Lk, ldq, \
                        heads, 0, ldo, nullptr, scale, out_split, split_c, parts)
-#define ALDM_ATTN_PRE2(Q_, P_)                                                                                         \
-    hipLaunchKernelGGL((attention_d32_presplit2_kernel<Q_, P_>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk, ldq, \
-                       heads, ldo, scale, out_split, split_c, parts)
-    if (sched2) {
+#define ALDM_ATTN_PRE2(K_, Q_, P_)                                                                                     \
+    hipLaunchKernelGGL((K_<Q_, P_>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk, ldq, heads, ldo, scale,  \
+                       out_split, split_c, parts)
+    if (sched == 2) {
         if (parts == 2) {
-            if (qt2) ALDM_ATTN_PRE2(2, 2);
-            else ALDM_ATTN_PRE2(1, 2);
+            if (qt2) ALDM_ATTN_PRE2(attention_d32_presplit3_kernel, 2, 2);
+            else ALDM_ATTN_PRE2(attention_d32_presplit3_kernel, 1, 2);
         } else {
-            if (qt2) ALDM_ATTN_PRE2(2, 3);
-            else ALDM_ATTN_PRE2(1, 3);
+            if (qt2) ALDM_ATTN_PRE2(attention_d32_presplit3_kernel, 2, 3);
+            else ALDM_ATTN_PRE2(attention_d32_presplit3_kernel, 1, 3);
+        }
+    } else if (sched == 1) {
+        if (parts == 2) {
+            if (qt2) ALDM_ATTN_PRE2(attention_d32_presplit2_kernel, 2, 2);
+            else ALDM_ATTN_PRE2(attention_d32_presplit2_kernel, 1, 2);
+        } else {
+            if (qt2) ALDM_ATTN_PRE2(attention_d32_presplit2_kernel, 2, 3);
+            else ALDM_ATTN_PRE2(attention_d32_presplit2_kernel, 1, 3);
         }
     } else if (parts == 2) {
         if (qt2) ALDM_ATTN_PRE(2, 2);

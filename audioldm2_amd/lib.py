@@ -150,14 +150,20 @@ EXPORTED_SYMBOLS = tuple(_SIGS.keys())
 _lib = None
 
 
-def source_hash() -> str:
+def source_hash(family: str = "all") -> str:
     """16 hex digits over the kernel sources and the ABI header: profile artefacts (profiles/*.json) carry it so a
-    reader — and bench.py — can tell whether they describe the code that is running."""
+    reader — and bench.py — can tell whether they describe the code that is running.  family = "igemm": only what the igemm
+    translation units are built from (igemm*.hip / igemm*.h, common.h, the ABI header) — the stamp of per-launch counters of
+    igemm kernels, which a change to another kernel family (attention, norms, decode) does not invalidate."""
     import glob
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
                    glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    if family == "igemm":
+        files = [f for f in files if os.path.basename(f).startswith("igemm") or os.path.basename(f) in ("common.h", "aldm_hip.h")]
+    elif family != "all":
+        raise ValueError(f"source_hash: unknown family {family!r}")
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:

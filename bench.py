@@ -348,13 +348,17 @@ def roofline_probe(ld, batch, B):
         ks = tj.get("kernels", {})
         cands = [k for k in ks if k == kname or k.startswith(kname[:-1] + ", ")]
         ent = ks[cands[0]] if len(cands) == 1 else None
-        if tj.get("source_hash") != source_hash():
+        # the records are per-launch counters of igemm kernels: they stand while the igemm sources (igemm*.hip / .h, common.h, the
+        # ABI header) are the ones the passes ran on, whatever happened to the other kernel families since
+        if tj.get("source_hash") != source_hash() and tj.get("igemm_source_hash") != source_hash("igemm"):
             # the PMC passes were collected on other kernel sources than the ones running now: not evidence for this line
             traffic_src = {"file": "profiles/" + os.path.basename(TRAFFIC_JSON), "stale": True,
-                           "file_source_hash": tj.get("source_hash"), "running_source_hash": source_hash()}
+                           "file_source_hash": tj.get("source_hash"), "running_source_hash": source_hash(),
+                           "file_igemm_source_hash": tj.get("igemm_source_hash"), "running_igemm_source_hash": source_hash("igemm")}
         elif ent:
             traffic = ent["hbm_bytes_per_launch"]
             traffic_src = {"file": "profiles/" + os.path.basename(TRAFFIC_JSON), "source_hash": tj["source_hash"],
+                           "igemm_source_hash": tj.get("igemm_source_hash"),
                            "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}

@@ -377,6 +377,135 @@ def test_qkv_epilogue_and_presplit_attention_are_bitwise_the_fp32_kv_path(ops, B
     assert rel_err(a_new, ref.transpose(1, 2).reshape(B, L, C)) < fused_tol()
 
 
+def _qkv_images(ops, q, k, v, heads):
+    """(q, k image, v^T image) of GIVEN q / k / v [B, L, C] through the QKV epilogue, plus the fp32 [q | k | v] the same projection
+    writes through the plain epilogue: the projection of [q | k | v] by the identity reproduces the values exactly in the 3-part
+    form (x_hi + x_mid + x_lo against 1.0) and as x_hi + x_mid in the 2-part form — the images hold exactly the returned values."""
+    B, L, C = q.shape
+    xs = ops.split_rows(torch.cat([q, k, v], -1).cuda())
+    pw = ops.pack_conv(torch.eye(3 * C))
+    return ops.linear_qkv(xs, pw, heads, L), ops.linear(xs, pw)
+
+
+def _late_large_scores(B, L, heads, jump):
+    """q, k, v [B, L, C] with keys planted in LATER key tiles whose scores lie jump * (q.u) log2 units above (q.u > 0) or below
+    (q.u < 0) everything else; a second, 1.5x larger key two tiles on.  The planted keys sit at in-tile indices 8 (held by the
+    lower lane half of the S^T layout), 4 and 31 (upper lane half)."""
+    C = heads * 32
+    q = torch.randn(B, L, C, generator=g(1))
+    k = torch.randn(B, L, C, generator=g(2))
+    v = torch.randn(B, L, C, generator=g(3))
+    u = torch.randn(heads, 32, generator=g(4))
+    u = u / u.norm(dim=-1, keepdim=True)
+    alpha = jump * math.sqrt(32.0) / 1.4426950408889634          # score of the planted key = jump * (q.u) in log2 units
+    late = {32: [(20, 1.0)], 64: [(40, 1.0), (63, 1.0)], 128: [(40, 1.0), (100, 1.5), (127, 1.5)]}[L]
+    if jump:
+        for pos, f in late:
+            k[:, pos, :] = (alpha * f * u).reshape(1, C)
+    return q, k, v
+
+
+@pytest.mark.parametrize("jump", [0.0, 12.0, 45.0, 70.0, 200.0])
+@pytest.mark.parametrize("B,L,heads", [(16, 128, 8), (2, 128, 2), (1, 64, 1), (1, 32, 1)])
+def test_attention_survives_late_large_scores(ops, B, L, heads, jump):
+    """Scores hundreds of log2 units above everything seen so far, arriving in a later key tile — and in EITHER lane half of the
+    S^T layout.  Until round 5 the pipelined kernels' cross-half exchange of the row maximum returned the LOWER half's value only
+    (a compiler quirk around __builtin_bit_cast of a vector element, csrc/attn.hip max_across_halves): the "running maximum" was
+    the maximum over half of each tile's keys — invisible while every key lay within 2^128 of it, non-finite output beyond (jump >=
+    70 here).  Both paths — fp32 K / V, and the pre-split images — against the fp64 softmax, to the fused tolerance plus the fp32
+    rounding of the scores themselves (2^-23 of the largest |score|: a dot product of that magnitude cannot be held tighter by ANY
+    fp32 accumulation), and bit-identical to each other.  (16, 128, 8) runs 64 queries per wave, the others 32."""
+    C = heads * 32
+    q, k, v = _late_large_scores(B, L, heads, jump)
+    (qi, kimg, vtimg), qkv = _qkv_images(ops, q, k, v, heads)
+    assert torch.equal(qi, qkv[..., :C].contiguous())
+    if exact_split(ops):
+        assert torch.equal(qkv.cpu(), torch.cat([q, k, v], -1))
+    a_new = ops.attention_presplit(qi, kimg, vtimg, heads)
+    a_old = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    sh = lambda t: t.double().cpu().view(B, L, heads, 32).transpose(1, 2)
+    qd, kd, vd = (sh(qkv[..., i * C:(i + 1) * C].contiguous()) for i in range(3))
+    sc = qd @ kd.transpose(-1, -2) / math.sqrt(32.0)
+    ref = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B, L, C)
+    score_tol = 2.0 ** -23 * float(sc.abs().max()) * 1.4426950408889634
+    assert torch.isfinite(a_new).all() and torch.isfinite(a_old).all()
+    assert torch.equal(a_new, a_old)
+    assert rel_err(a_new, ref) < fused_tol() + score_tol
+
+
+@pytest.mark.parametrize("idx", [0, 4, 8, 15, 16, 23, 27, 31])
+@pytest.mark.parametrize("tile", [0, 3])
+def test_attention_row_maximum_covers_every_key_position(ops, tile, idx):
+    """One key 200 log2 units above the rest at in-tile index `idx` of the first / last key tile (indices 4-7, 12-15, 20-23, 28-31
+    are held by the upper lane half): the output is that key's value row, from both kernels."""
+    B, L, heads = 1, 128, 2
+    C = heads * 32
+    q = torch.zeros(B, L, C)
+    q[..., 0] = 1.0
+    q[..., 32] = 1.0
+    k = torch.zeros(B, L, C)
+    k[0, 32 * tile + idx, 0] = k[0, 32 * tile + idx, 32] = 200.0 * math.sqrt(32.0) / 1.4426950408889634
+    v = torch.randn(B, L, C, generator=g(5))
+    (qi, kimg, vtimg), qkv = _qkv_images(ops, q, k, v, heads)
+    a_new = ops.attention_presplit(qi, kimg, vtimg, heads)
+    a_old = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    want = qkv[0, 32 * tile + idx, 2 * C:].expand(L, C)
+    assert torch.equal(a_new[0], want) and torch.equal(a_old[0], want)
+
+
+@pytest.mark.parametrize("sched", ["0", "2"])
+def test_presplit_kernels_selected_by_env_agree_with_the_default(sched):
+    """ALDM_ATTN_SCHED is read once per process: a fresh one for 0 (the round-3 / 4 pipelined kernel: BIT-identical to the fp32-K/V
+    path, like the default) and 2 (the opt-in one-pass loop with a fixed softmax reference per row: its probabilities differ from
+    the exact-max kernels' by one common factor per row that cancels in O / l — equal to fp32 rounding, measured 4e-7 .. 1.8e-6
+    of max |out| in the 6-product mode and <= 1e-5 with 2-part operands; its slow path — reference raised when a tile's row sum
+    passes 2^60, exponentials that overflowed recomputed from the intact scores — is what the large jumps exercise)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import math, sys, torch
+sys.path.insert(0, "tests")
+from test_dma_gpu import _late_large_scores, _qkv_images
+from audioldm2_amd import ops
+for (B, L, heads), jump in [((16, 1024, 8), 0.0), ((3, 64, 20), 0.0), ((2, 96, 2), 0.0), ((2, 32, 2), 0.0), ((16, 128, 8), 12.0),
+                            ((16, 128, 8), 70.0), ((2, 128, 2), 200.0), ((1, 64, 1), 200.0), ((1, 32, 1), 200.0)]:
+    C = heads * 32
+    if L in (32, 64, 128):
+        q, k, v = _late_large_scores(B, L, heads, jump)
+    else:
+        q, k, v = (torch.randn(B, L, C, generator=torch.Generator().manual_seed(i)) for i in (1, 2, 3))
+    (qi, kimg, vtimg), qkv = _qkv_images(ops, q, k, v, heads)
+    a_new = ops.attention_presplit(qi, kimg, vtimg, heads)
+    a_old = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads)
+    sh = lambda t: t.double().cpu().view(B, L, heads, 32).transpose(1, 2)
+    qd, kd, vd = (sh(qkv[..., i * C:(i + 1) * C].contiguous()) for i in range(3))
+    sc = qd @ kd.transpose(-1, -2) / math.sqrt(32.0)
+    ref = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B, L, C)
+    rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+    print("CASE", B, L, heads, jump, int(torch.isfinite(a_new).all()), int(torch.equal(a_new, a_old)), rel(a_new, a_old), rel(a_new, ref),
+          2.0 ** -23 * float(sc.abs().max()) * 1.4426950408889634)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("bf16x6", "bf16x3"):
+        env = dict(os.environ, ALDM_MMA=mode, ALDM_ATTN_SCHED=sched, PYTHONPATH=root)
+        env.pop("ALDM_ATTN_MMA", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("CASE")]
+        assert len(lines) == 9, out.stdout[-2000:]
+        grade = 5e-6 if mode == "bf16x6" else 5e-5
+        for B, L, heads, jump, finite, bitwise, d_old, d_ref, score_tol in lines:
+            what = (mode, sched, B, L, heads, jump)
+            assert finite == "1", what
+            log_err(float(d_ref), grade + float(score_tol), f"attention ALDM_ATTN_SCHED={sched} {mode} vs fp64")
+            assert float(d_ref) < grade + float(score_tol), what
+            if sched == "0":
+                assert bitwise == "1", what
+            else:
+                assert float(d_old) < (3e-6 if mode == "bf16x6" else 3e-5) + float(score_tol), what
+
+
 # ---- the operand-stationary form for short K (csrc/igemm_dma_os.h): aldm_igemm_force(32, 128, ..., 300 + ring depth) ------------
 # Same products in the same order per k-tile as igemm_dma_kernel, but accumulated by v_mfma_f32_16x16x32_bf16 (32 k per
 # instruction) instead of two chained 32x32x16 ones: equal to fp32 rounding, not bitwise.

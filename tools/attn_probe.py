@@ -1,7 +1,8 @@
 """Per-launch time of the pre-split self-attention kernel at the UNet's geometries (16 samples per pass), HIP-graph timed, for
-the library named by $ALDM_LIB_PATH and the kernel selected by $ALDM_ATTN_SCHED (0 = the round-3/4 pipelined kernel, unset = the
-round-5 re-scheduled one) — one process per arm (both switches are read once).  Also checks the result against fp64 and against
-the fp32-K/V path bitwise.  Usage: [ALDM_LIB_PATH=...] [ALDM_ATTN_SCHED=0] [ALDM_MMA=bf16x3] python tools/attn_probe.py"""
+the library named by $ALDM_LIB_PATH and the kernel selected by $ALDM_ATTN_SCHED (0 = the round-3/4 pipelined kernel, unset / 1 = the
+round-5 re-scheduled exact-max loop, 2 = the opt-in one-pass fixed-reference loop) — one process per arm (both switches are read
+once).  Also checks the result against fp64 and against the fp32-K/V path (bitwise for 0 / 1; to fp32 rounding for 2).
+Usage: [ALDM_LIB_PATH=...] [ALDM_ATTN_SCHED=0|2] [ALDM_MMA=bf16x3] python tools/attn_probe.py"""
 import os
 import sys
 
@@ -47,11 +48,12 @@ for B, H, L in GEOMS:
     qkv = ops.linear(xs, pw)
     o_ref = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], H)
     bit = bool(torch.equal(out, o_ref))
+    dif = float((out.double() - o_ref.double()).abs().max() / o_ref.double().abs().max())
     sh = lambda t: t.double().cpu().view(B, L, H, 32).transpose(1, 2)
     qd, kd, vd = (sh(qkv[..., i * C:(i + 1) * C].contiguous()) for i in range(3))
     ref = (torch.softmax(qd @ kd.transpose(-1, -2) / 32 ** 0.5, -1) @ vd).transpose(1, 2).reshape(B, L, C)
     err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
     us = timed(lambda: ops.attention_presplit(q, k_img, vt_img, H))
     fl = 4.0 * B * H * L * L * 32
-    print(f"{tag}: {B} x {H} heads x {L} x {L}: {us:7.2f} us  {fl / us * 1e-6:6.1f} TFLOP/s  err vs fp64 {err:.2e}  bitwise vs fp32-KV path {bit}",
+    print(f"{tag}: {B} x {H} heads x {L} x {L}: {us:7.2f} us  {fl / us * 1e-6:6.1f} TFLOP/s  err vs fp64 {err:.2e}  vs fp32-KV path: bitwise {bit}, max diff {dif:.1e}",
           flush=True)
