@@ -387,6 +387,13 @@ def _qkv_images(ops, q, k, v, heads):
     return ops.linear_qkv(xs, pw, heads, L), ops.linear(xs, pw)
 
 
+def _score_tol(fp32_grade, smax):
+    """What the rounding of a score of magnitude smax (natural units) costs the softmax, relative to max |out|: the 6-product form
+    holds a dot product to ~2^-26 of its magnitude (measured 4e-9 per log2 unit of the largest score: 6.0e-6 at 1180), the
+    3-product form with its 16-bit operands to ~2^-20 (measured 2.2e-7 .. 3.4e-7 per unit: 2.9e-4 at 930).  Bars <= 5x measured."""
+    return (2.0 ** -26 if fp32_grade else 2.0 ** -20) * smax * 1.4426950408889634
+
+
 def _late_large_scores(B, L, heads, jump):
     """q, k, v [B, L, C] with keys planted in LATER key tiles whose scores lie jump * (q.u) log2 units above (q.u > 0) or below
     (q.u < 0) everything else; a second, 1.5x larger key two tiles on.  The planted keys sit at in-tile indices 8 (held by the
@@ -406,15 +413,15 @@ def _late_large_scores(B, L, heads, jump):
 
 
 @pytest.mark.parametrize("jump", [0.0, 12.0, 45.0, 70.0, 200.0])
-@pytest.mark.parametrize("B,L,heads", [(16, 128, 8), (2, 128, 2), (1, 64, 1), (1, 32, 1)])
+@pytest.mark.parametrize("B,L,heads", [(16, 128, 8), (2, 128, 2), (1, 64, 2), (1, 32, 2)])
 def test_attention_survives_late_large_scores(ops, B, L, heads, jump):
     """Scores hundreds of log2 units above everything seen so far, arriving in a later key tile — and in EITHER lane half of the
     S^T layout.  Until round 5 the pipelined kernels' cross-half exchange of the row maximum returned the LOWER half's value only
     (a compiler quirk around __builtin_bit_cast of a vector element, csrc/attn.hip max_across_halves): the "running maximum" was
     the maximum over half of each tile's keys — invisible while every key lay within 2^128 of it, non-finite output beyond (jump >=
-    70 here).  Both paths — fp32 K / V, and the pre-split images — against the fp64 softmax, to the fused tolerance plus the fp32
-    rounding of the scores themselves (2^-23 of the largest |score|: a dot product of that magnitude cannot be held tighter by ANY
-    fp32 accumulation), and bit-identical to each other.  (16, 128, 8) runs 64 queries per wave, the others 32."""
+    70 here).  Both paths — fp32 K / V, and the pre-split images — against the fp64 softmax, to the fused tolerance plus the
+    rounding of the scores themselves, which grows with their magnitude (_score_tol), and bit-identical to each other.
+    (16, 128, 8) runs 64 queries per wave, the others 32."""
     C = heads * 32
     q, k, v = _late_large_scores(B, L, heads, jump)
     (qi, kimg, vtimg), qkv = _qkv_images(ops, q, k, v, heads)
@@ -427,10 +434,9 @@ def test_attention_survives_late_large_scores(ops, B, L, heads, jump):
     qd, kd, vd = (sh(qkv[..., i * C:(i + 1) * C].contiguous()) for i in range(3))
     sc = qd @ kd.transpose(-1, -2) / math.sqrt(32.0)
     ref = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B, L, C)
-    score_tol = 2.0 ** -23 * float(sc.abs().max()) * 1.4426950408889634
     assert torch.isfinite(a_new).all() and torch.isfinite(a_old).all()
     assert torch.equal(a_new, a_old)
-    assert rel_err(a_new, ref) < fused_tol() + score_tol
+    assert rel_err(a_new, ref) < fused_tol() + _score_tol(exact_split(ops), float(sc.abs().max()))
 
 
 @pytest.mark.parametrize("idx", [0, 4, 8, 15, 16, 23, 27, 31])
@@ -458,7 +464,7 @@ def test_presplit_kernels_selected_by_env_agree_with_the_default(sched):
     """ALDM_ATTN_SCHED is read once per process: a fresh one for 0 (the round-3 / 4 pipelined kernel: BIT-identical to the fp32-K/V
     path, like the default) and 2 (the opt-in one-pass loop with a fixed softmax reference per row: its probabilities differ from
     the exact-max kernels' by one common factor per row that cancels in O / l — equal to fp32 rounding, measured 4e-7 .. 1.8e-6
-    of max |out| in the 6-product mode and <= 1e-5 with 2-part operands; its slow path — reference raised when a tile's row sum
+    of max |out| in the 6-product mode and <= 1e-5 with 2-part operands, plus _score_tol under extreme scores; its slow path — reference raised when a tile's row sum
     passes 2^60, exponentials that overflowed recomputed from the intact scores — is what the large jumps exercise)."""
     import os
     import subprocess
@@ -469,7 +475,7 @@ sys.path.insert(0, "tests")
 from test_dma_gpu import _late_large_scores, _qkv_images
 from audioldm2_amd import ops
 for (B, L, heads), jump in [((16, 1024, 8), 0.0), ((3, 64, 20), 0.0), ((2, 96, 2), 0.0), ((2, 32, 2), 0.0), ((16, 128, 8), 12.0),
-                            ((16, 128, 8), 70.0), ((2, 128, 2), 200.0), ((1, 64, 1), 200.0), ((1, 32, 1), 200.0)]:
+                            ((16, 128, 8), 70.0), ((2, 128, 2), 200.0), ((1, 64, 2), 200.0), ((1, 32, 2), 200.0)]:
     C = heads * 32
     if L in (32, 64, 128):
         q, k, v = _late_large_scores(B, L, heads, jump)
@@ -484,7 +490,7 @@ for (B, L, heads), jump in [((16, 1024, 8), 0.0), ((3, 64, 20), 0.0), ((2, 96, 2
     ref = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B, L, C)
     rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
     print("CASE", B, L, heads, jump, int(torch.isfinite(a_new).all()), int(torch.equal(a_new, a_old)), rel(a_new, a_old), rel(a_new, ref),
-          2.0 ** -23 * float(sc.abs().max()) * 1.4426950408889634)
+          float(sc.abs().max()))
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("bf16x6", "bf16x3"):
@@ -495,15 +501,17 @@ for (B, L, heads), jump in [((16, 1024, 8), 0.0), ((3, 64, 20), 0.0), ((2, 96, 2
         lines = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("CASE")]
         assert len(lines) == 9, out.stdout[-2000:]
         grade = 5e-6 if mode == "bf16x6" else 5e-5
-        for B, L, heads, jump, finite, bitwise, d_old, d_ref, score_tol in lines:
+        for B, L, heads, jump, finite, bitwise, d_old, d_ref, smax in lines:
             what = (mode, sched, B, L, heads, jump)
+            score_tol = _score_tol(mode == "bf16x6", float(smax))
             assert finite == "1", what
-            log_err(float(d_ref), grade + float(score_tol), f"attention ALDM_ATTN_SCHED={sched} {mode} vs fp64")
-            assert float(d_ref) < grade + float(score_tol), what
+            log_err(float(d_ref), grade + score_tol, f"attention ALDM_ATTN_SCHED={sched} {mode} vs fp64")
+            assert float(d_ref) < grade + score_tol, what
             if sched == "0":
                 assert bitwise == "1", what
             else:
-                assert float(d_old) < (3e-6 if mode == "bf16x6" else 3e-5) + float(score_tol), what
+                log_err(float(d_old), (3e-6 if mode == "bf16x6" else 3e-5) + score_tol, f"attention ALDM_ATTN_SCHED=2 {mode} vs the exact-max kernel")
+                assert float(d_old) < (3e-6 if mode == "bf16x6" else 3e-5) + score_tol, what
 
 
 # ---- the operand-stationary form for short K (csrc/igemm_dma_os.h): aldm_igemm_force(32, 128, ..., 300 + ring depth) ------------
