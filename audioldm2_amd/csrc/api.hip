@@ -12,5 +12,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace aldm
 
-extern "C" int aldm_version(void) { return 8; }
+extern "C" int aldm_version(void) { return 9; }
 extern "C" const char* aldm_last_error(void) { return aldm::g_err; }

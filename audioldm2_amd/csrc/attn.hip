@@ -1362,6 +1362,15 @@ extern "C" int aldm_attention_mma(int mode) {
     return g_attn_mma.load();
 }
 
+// schedule of the pre-split self-attention kernel (aldm_attention_d32_presplit): -1 = default ($ALDM_ATTN_SCHED, read once, else 1);
+// 0 = the round-3 / 4 pipelined kernel, 1 = the re-scheduled exact-max loop, 2 = the one-pass fixed-reference loop.  Process wide,
+// like the product mode (an env-only switch could not be A/B-ed inside one test process).
+static std::atomic<int> g_attn_sched{-1};
+extern "C" int aldm_attention_sched(int sched) {
+    if (sched >= -1 && sched <= 3) return g_attn_sched.exchange(sched);
+    return g_attn_sched.load();
+}
+
 static int attention_launch(const float* q, const float* k, const float* v, float* out, void* out_split, int parts, int B,
                             int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo,
                             const float* mask, float scale, void* stream) {
@@ -1456,10 +1465,12 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
     // (attention_d32_presplit2_kernel; bitwise the fp32-K/V path), 0 = the round-3 / 4 pipelined kernel (bitwise too), 2 = the
     // one-pass fixed-reference loop (attention_d32_presplit3_kernel: -26 % VALU instructions for -3 % time and 1.7x the error —
     // the experiment that showed what bounds this loop; kept opt-in for its ablation builds)
-    static const int sched = [] {
+    static const int env_sched = [] {
         const char* e = getenv("ALDM_ATTN_SCHED");
-        return e == nullptr ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1));
+        return e == nullptr ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : (e[0] == '3' ? 3 : 1)));
     }();
+    const int gs = g_attn_sched.load();
+    const int sched = gs < 0 ? env_sched : gs;
 #define ALDM_ATTN_PRE(Q_, P_)                                                                                          \
     hipLaunchKernelGGL((attention_d32_pipe_kernel<false, Q_, P_, true>), grid, dim3(256), 0, st, q, kf, vf, out, Lq, Lk, ldq, \
                        heads, 0, ldo, nullptr, scale, out_split, split_c, parts)

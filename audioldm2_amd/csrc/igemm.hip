@@ -23,7 +23,9 @@ int igemm_launch_bx_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 gr
 // DMA-fed kernel over pre-split operands (igemm_dma.hip)
 int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_config_ok(int BM, int BN, int nst, int parts);
-extern std::atomic<int> g_debug_drop_product;   // test hook, igemm_dma.hip
+#ifdef ALDM_TEST_HOOKS
+extern std::atomic<int> g_debug_drop_product;   // test hook, igemm_dma.hip (libaldm_hip_testhooks.so only)
+#endif
 // ... and its persistent wave-specialised form (igemm_dma_ws.hip)
 int igemm_launch_dma_ws(int BM, int BN, int nst, int parts, int blocks, hipStream_t st, const IgemmK& p);
 bool igemm_dma_ws_config_ok(int BM, int BN, int nst, int parts);
@@ -702,10 +704,12 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
     // BX: the 128x128 image leaves room for one block per CU, so that tile takes 8 waves for every prologue
     const bool w8 = p.kgroups == 1 && d.epi_mode != ALDM_EPI_GEGLU && (env_w8 & tile_bit) != 0 &&
                     (p.bx ? tile_bit == 1 : (gn_pre || (tile_bit == 1 && (env_w8 & 8) != 0)));
+#ifdef ALDM_TEST_HOOKS
     if (g_debug_drop_product.load(std::memory_order_relaxed))   // test hook: only the classic DMA-fed 64x128 tile has a 5-product form
         ALDM_CHECK(p.dma && p.ws == 0 && BM == 64 && BN == 128 && p.nst == 2 && d.split_parts == 3,
                    "aldm_igemm: aldm_debug_drop_product is set: force the classic DMA-fed 64x128 tile with 2 stages and 3-part images "
                    "(got dma=%d form=%d tile %dx%d, %d stages, %d parts) or clear the switch", p.dma, p.ws, BM, BN, p.nst, d.split_parts);
+#endif
     if (p.dma && p.ws == 3) {
         rc = igemm_launch_dma_os(d.K / 32, p.nst, d.split_parts, grid, st, p);
     } else if (p.dma && p.ws == 2) {

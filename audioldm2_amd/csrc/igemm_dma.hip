@@ -15,15 +15,20 @@ bool igemm_dma_config_ok(int BM, int BN, int nst, int parts) {
     return false;
 }
 
-// test hook (aldm_debug_drop_product, include/aldm_hip.h): non-zero -> DMA-fed launches run the 5-product kernel or fail
+#ifdef ALDM_TEST_HOOKS
+// test hook (aldm_debug_drop_product, include/aldm_hip.h; libaldm_hip_testhooks.so only): non-zero -> DMA-fed launches run the
+// 5-product kernel or fail.  The release library has neither the switch nor the broken instantiation.
 std::atomic<int> g_debug_drop_product{0};
+#endif
 
 int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+#ifdef ALDM_TEST_HOOKS
     if (g_debug_drop_product.load(std::memory_order_relaxed)) {   // (aldm_igemm has checked the tile)
         if (!(BM == 64 && BN == 128 && nst == 2 && parts == 3)) return -1;
         hipLaunchKernelGGL((igemm_dma_kernel<64, 128, 2, 2, 3, true>), grid, dim3(256), 0, st, p);
         return 0;
     }
+#endif
 #define ALDM_DMA(BM_, BN_, NST_, NP_) \
     hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 2, NP_>), grid, dim3(256), 0, st, p)
 #define ALDM_DMA8(BM_, BN_, NST_, NP_) \
@@ -125,8 +130,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 
 using namespace aldm;
 
-namespace aldm { extern std::atomic<int> g_debug_drop_product; }
+#ifdef ALDM_TEST_HOOKS
 extern "C" int aldm_debug_drop_product(int on) { return aldm::g_debug_drop_product.exchange(on ? 1 : 0); }
+#endif
 
 extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C, int parts) { return rows * (int64_t)(C / 32) * 64 * parts; }
 

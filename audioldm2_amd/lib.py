@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALDM_LIB_PATH") or os.path.join(_HERE, "libaldm_hip.so")  # override: debug builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU, ACT_GELU_TANH = range(7)
 B_PACKED, B_NT = 0, 1
@@ -76,7 +76,6 @@ _SIGS = {
     "aldm_split_bytes_parts": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "aldm_pack_split_bf16_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aldm_igemm_mma": (C.c_int, [C.c_int]),
-    "aldm_debug_drop_product": (C.c_int, [C.c_int]),
     "aldm_split_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "aldm_pack_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "aldm_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -93,6 +92,7 @@ _SIGS = {
     "aldm_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_void_p]),
     "aldm_attention_mma": (C.c_int, [C.c_int]),
+    "aldm_attention_sched": (C.c_int, [C.c_int]),
     "aldm_attention_d32_presplit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -146,6 +146,9 @@ _SIGS = {
 
 # every symbol include/aldm_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+# ... and what only the -DALDM_TEST_HOOKS variant (libaldm_hip_testhooks.so, loaded through $ALDM_LIB_PATH by one test) adds
+TEST_HOOK_SIGS = {"aldm_debug_drop_product": (C.c_int, [C.c_int])}
+TESTHOOKS_LIB_PATH = os.path.join(_HERE, "libaldm_hip_testhooks.so")
 
 _lib = None
 
@@ -187,6 +190,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in TEST_HOOK_SIGS.items():   # bound only when the loaded library is the test-hook variant
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     ver = lib.aldm_version()
     if ver != ABI_VERSION:
         raise RuntimeError(f"libaldm_hip.so ABI version {ver} != expected {ABI_VERSION}; rebuild")

@@ -369,11 +369,22 @@ def attention_mma(mode: int) -> int:
     return _l.load().aldm_attention_mma(mode)
 
 
+def attention_sched(sched: int) -> int:
+    """Schedule of the pre-split self-attention kernel (aldm_attention_sched): -1 default, 0 round-3/4 pipelined, 1 re-scheduled
+    exact-max loop, 2 one-pass fixed-reference loop, 3 K / V^T through LDS once per block.  Returns the previous setting."""
+    return _l.load().aldm_attention_sched(sched)
+
+
 def debug_drop_product(on: bool) -> bool:
     """TEST HOOK (aldm_debug_drop_product): DMA-fed launches leave out the smallest of the six bf16 partial products — only the
     classic 64x128 / 2-stage tile has that instantiation, every other igemm launch fails while the switch is on.  Returns the
-    previous setting.  Used by tests/test_dma_gpu.py to show the fp32-grade bar catches a lost product."""
-    return bool(_l.load().aldm_debug_drop_product(1 if on else 0))
+    previous setting.  Used by tests/test_dma_gpu.py to show the fp32-grade bar catches a lost product.  The symbol exists only in the
+    -DALDM_TEST_HOOKS variant library (libaldm_hip_testhooks.so, selected with $ALDM_LIB_PATH): on the release library this raises."""
+    fn = getattr(_l.load(), "aldm_debug_drop_product", None)
+    if fn is None:
+        raise RuntimeError("aldm_debug_drop_product is a test hook of libaldm_hip_testhooks.so; the release library does not "
+                           f"export it (run with ALDM_LIB_PATH={_l.TESTHOOKS_LIB_PATH})")
+    return bool(fn(1 if on else 0))
 
 
 def igemm_mma(mode: int) -> int:

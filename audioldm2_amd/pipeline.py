@@ -675,7 +675,6 @@ class LatentDiffusion(nn.Module):
                           "had no `clap.*` entries): candidates are ranked by a randomly initialised model")
             self._warned_clap_random = True
 
-    @torch.no_grad()
     def _cfg_dropout_draw(self):
         """RNG contract R, the draw nobody asked for: `LatentDiffusion.get_input` (ddpm.py:850-855) asks
         `make_decision(unconditional_prob_cfg)` = `float(torch.rand(1)) < p` whether to drop the conditioning — but only `if
@@ -684,10 +683,11 @@ class LatentDiffusion(nn.Module):
         still happens, between the posterior sample and the conditioners, on every call except an object's first — and shifts every later
         random number of the job.  A process that calls `text_to_audio` twice with the same seed therefore gets two different clips from
         the reference (found in round 5 by tools/parity_on_checkpoint.py running two jobs in one process); so does this class."""
-        if self.conditional_dry_run_finished:
+        if self.conditional_dry_run_finished and len(self.cond_stage_model_metadata) > 0:   # ddpm.py:850: only with conditioners
             torch.rand(1)
-        self.conditional_dry_run_finished = True
+        self.conditional_dry_run_finished = True   # ddpm.py:916: unconditionally
 
+    @torch.no_grad()
     def generate_batch(self, batch, ddim_steps=200, ddim_eta=1.0, x_T=None, n_gen=1,
                        unconditional_guidance_scale=1.0, unconditional_conditioning=None, use_plms=False,
                        **kwargs):

@@ -267,10 +267,13 @@ class Sequence2AudioMAE(nn.Module):
             e["slot"] += 1
         run = GraphStepper(step, use_graph=x.is_cuda and steps >= self.GRAPH_MIN_STEPS and
                            os.environ.get("ALDM_NO_GRAPH", "0") != "1")
-        for _ in range(steps - 1):
-            run()
-        run.fn = None          # break the closure cycle: the graph and its pool go with this call, not with a later collection
-        run.graph = None
+        try:
+            for _ in range(steps - 1):
+                run()
+        finally:
+            run.fn = None          # break the closure cycle: the graph and its pool go with this call, not with a later collection
+            run.graph = None
+            self._decode_fast = None   # a later direct `_decode_one` reads $ALDM_SEQGEN_DECODE again
         return toks, cond_dict
 
     # ---- conditioning through the sub-modules (sequence_input.py:327-370, 385-403) ---------------------------------

@@ -504,7 +504,6 @@ class UNetModel(nn.Module):
         return self._pk
 
     # -- forward -----------------------------------------------------------------------------------
-    @torch.no_grad()
     def _shared_prefix_end(self, context_list):
         """(input block, layer) of the first SpatialTransformer that receives a context — where the two halves of a
         classifier-free-guidance batch start to differ (TimestepEmbedSequential: the first transformer of a block never gets a
@@ -521,6 +520,7 @@ class UNetModel(nn.Module):
                     st += 1
         return None
 
+    @torch.no_grad()
     def forward(self, x, timesteps=None, y=None, context_list=None, context_attn_mask_list=None, cfg_shared=False, **kwargs):
         """openaimodel.py:837-885.  x: [N, C, H, W] fp32 on the GPU; returns eps [N, C_out, H, W] (cfg_shared: x [B, ...] once for
         the 2B rows [uncond ; cond] of a classifier-free-guidance pass, returns eps [2B, ...]; see below)."""

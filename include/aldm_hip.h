@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* ---- library / error ------------------------------------------------------------------ */
-int aldm_version(void);              /* ABI version (8), bumped on any struct / entry change */
+int aldm_version(void);              /* ABI version (9), bumped on any struct / entry change */
 const char* aldm_last_error(void);   /* message of the last failing call on this thread     */
 
 /* ---- activations usable as prologue (applied to the gathered input) or epilogue -------- */
@@ -207,12 +207,16 @@ int aldm_igemm_wave8_mask(int mask);
  * carries w_split and the tuned hint allows), 1 = fp32 MFMA always, 2 = bf16-split wherever an instantiation
  * exists.  Returns the previous mode; other values only query.                                            */
 int aldm_igemm_mma(int mode);
-/* TEST HOOK, process wide: on != 0 makes DMA-fed launches leave out the smallest of the six bf16 partial products (hi_a x
- * lo_w) — a deliberately broken "5-product" GEMM, ~1e-5 off — so that tests/test_dma_gpu.py can show that the fp32-grade
- * tolerance WOULD catch a kernel that silently lost a product.  Only the classic 64x128 tile with 2 stages
- * and 3-part images has that instantiation: while the switch is on every other aldm_igemm launch FAILS (nothing runs at full
- * precision by accident).  Returns the previous setting.  No product code path sets it.                              */
+#ifdef ALDM_TEST_HOOKS
+/* TEST HOOK — NOT in libaldm_hip.so (ABI v9).  It exists only in the variant library libaldm_hip_testhooks.so, which the build
+ * compiles from the same sources with -DALDM_TEST_HOOKS and which tests/test_dma_gpu.py loads in a subprocess through
+ * $ALDM_LIB_PATH.  Process wide: on != 0 makes DMA-fed launches leave out the smallest of the six bf16 partial products (hi_a x
+ * lo_w) — a deliberately broken "5-product" GEMM, ~1e-5 off — so that the test can show that the fp32-grade tolerance WOULD catch
+ * a kernel that silently lost a product.  Only the classic 64x128 tile with 2 stages and 3-part images has
+ * that instantiation: while the switch is on every other aldm_igemm launch FAILS (nothing runs at full precision by accident).
+ * Returns the previous setting.                                                                                          */
 int aldm_debug_drop_product(int on);
+#endif
 /* bf16-split image of a packed weight [ceil(K/4)][Npad][4] (aldm_pack_weight / aldm_pack_kn output) for
  * aldm_igemm_desc.w_split: [4*ceil(K/32) k-octets][3 parts][Npad][8 bf16], w = hi + mid + lo exactly.
  * aldm_split_bytes = size of that image.                                                                 */
@@ -304,6 +308,11 @@ int aldm_attention_d32_presplit(const float* q, const void* k_split, const void*
  * default: $ALDM_ATTN_MMA if set, else the engine's $ALDM_MMA, else bf16x6 ("f32" | "bf16x6" | "bf16x3"; anything else is
  * reported on stderr and ignored).  Returns the previous mode; other values only query.                         */
 int aldm_attention_mma(int mode);
+/* Schedule of aldm_attention_d32_presplit (tests / tools; process wide): -1 = default ($ALDM_ATTN_SCHED, else 1), 0 = the round-3/4
+ * pipelined kernel, 1 = the re-scheduled exact-max loop (bitwise the fp32-K/V path), 2 = the one-pass loop with a fixed softmax
+ * reference per row (opt-in experiment, 1.7x the error), 3 = K / V^T tiles shared by a block's waves through LDS (ABI v9).
+ * Returns the previous setting; other values only query.                                                                  */
+int aldm_attention_sched(int sched);
 /* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,
  * window_size = `window` <= 8, shared heads): per head h (channels [h*d, (h+1)*d), d <= 128)
  *   s[i, j] = (q_i/sqrt(d)).k_j + [|j-i| <= window] (q_i/sqrt(d)).emb_k[j-i+window];  s = -1e4 where mask_i*mask_j == 0;

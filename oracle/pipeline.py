@@ -79,9 +79,9 @@ class OracleLatentDiffusion:
     def _cfg_dropout_draw(self):
         """ddpm.py:850-855, 916-917: `get_input` draws `torch.rand(1)` (make_decision(unconditional_prob_cfg), always "no" at p = 0.0)
         on every call except the first of the object's life — between the posterior sample and the conditioners."""
-        if self.conditional_dry_run_finished:
+        if self.conditional_dry_run_finished and len(self.cond_keys) > 0:   # ddpm.py:850: `if len(cond_stage_model_metadata) > 0`
             torch.rand(1)
-        self.conditional_dry_run_finished = True
+        self.conditional_dry_run_finished = True   # ddpm.py:916: unconditionally
 
     def apply_model(self, x, t, cond):
         # DiffusionWrapper.forward (ddpm.py:1821-1879): film* keys -> y (squeeze(1), concatenated),

@@ -13,9 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "aldm_hip.h")
 
 
-def declared_functions():
+def declared_functions(test_hooks=False):
+    """Entry points the header declares for the release library (test_hooks: only those under #ifdef ALDM_TEST_HOOKS)."""
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    hooks = "".join(re.findall(r"#ifdef ALDM_TEST_HOOKS(.*?)#endif", src, flags=re.S))
+    if test_hooks:
+        src = hooks
+    else:
+        src = re.sub(r"#ifdef ALDM_TEST_HOOKS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(aldm_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -28,6 +34,22 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, n), f"{n} declared in include/aldm_hip.h but not exported"
     assert sorted(lib.EXPORTED_SYMBOLS) == names, "lib.py signature table out of sync with the header"
     assert l.aldm_version() == lib.ABI_VERSION
+
+
+def test_test_hooks_live_in_the_variant_library_only():
+    """the precision-breaking switch is not in the shipped library.  libaldm_hip_testhooks.so (same sources,
+    -DALDM_TEST_HOOKS) exports everything the release library does plus the hooks; the release library exports none of them."""
+    from audioldm2_amd import lib
+    hooks = declared_functions(test_hooks=True)
+    assert hooks == sorted(lib.TEST_HOOK_SIGS) == ["aldm_debug_drop_product"]
+    rel = lib.load()
+    var = ctypes.CDLL(lib.TESTHOOKS_LIB_PATH)
+    for n in hooks:
+        assert not hasattr(rel, n), f"{n} must not be exported by libaldm_hip.so"
+        assert hasattr(var, n)
+    for n in declared_functions():
+        assert hasattr(var, n)
+    assert var.aldm_version() == lib.ABI_VERSION
 
 
 def test_igemm_desc_layout_matches_c_struct(tmp_path):
