@@ -37,6 +37,10 @@ bool igemm_dma_lw_config_ok(int BM, int BN, int nst, int parts);
 int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_os_config_ok(int KT, int nst, int parts);
 int igemm_dma_os_default_stages(int KT, int parts);
+// ... and the halo-patch form for 3x3 / stride-1 / pad-1 convolutions (igemm_dma_halo.hip): the A patch of a 32-channel block is
+// staged in LDS once for all nine taps
+int igemm_launch_dma_halo(int BM, int BN, int nstb, int wm, int parts, int maxch, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_dma_halo_maxch(int BM, int BN, int nstb, int wm, int parts, int nch);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
 // quad (N % 4 == 0 is required for split-K).
@@ -279,6 +283,17 @@ static bool dma_os_eligible(const IgemmK& p) {
     return true;
 }
 
+// the halo-patch kernel (igemm_dma_halo.h) runs 3x3 convolutions with stride 1, padding 1, no dilation / upsample / row remap whose
+// BM-row tiles are whole image rows of one image (W a power of two dividing BM, OH * OW a multiple of BM); returns the 16-pixel
+// chunks per part of its patch, 0 when the launch does not qualify
+static int dma_halo_chunks(const IgemmK& p, int BM) {
+    const aldm_igemm_desc& d = p.d;
+    if (d.KH != 3 || d.KW != 3 || d.SH != 1 || d.SW != 1 || d.PH != 1 || d.PW != 1 || d.DH != 1 || d.DW != 1) return 0;
+    if (d.up_h != 1 || d.up_w != 1 || d.OH != d.H || d.OW != d.W || d.out_mul > 0 || d.batch > 1) return 0;
+    if (d.W <= 0 || (d.W & (d.W - 1)) != 0 || BM % d.W != 0 || p.OHW % BM != 0) return 0;
+    return ((BM / d.W + 2) * d.W + 15) / 16;
+}
+
 static bool tile_supported(int BM, int BN) {
     return (BM == 128 && (BN == 128 || BN == 64 || BN == 32)) || (BM == 64 && (BN == 128 || BN == 64));
 }
@@ -428,8 +443,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         int f_st = g_force_bm ? g_force_stages : (hint_fits ? d.hint_stages : 0);
         int ws_nst = 0;   // stages in [100, 200): the persistent wave-specialised kernel with a ring of (stages - 100)
         int lw_nst = 0;   // stages in [200, 300): igemm_dma_kernel with loader waves, ring of (stages - 200)
-        if (f_st >= 300) {
-            // stages >= 300: the operand-stationary kernel, ring of (stages - 300) 32-row stages (300 itself: the deepest ring that
+        if (f_st >= 300 && f_st < 400) {
+            // stages 300 .. 399: the operand-stationary kernel, ring of (stages - 300) 32-row stages (300 itself: the deepest ring that
             // fits).  A launch it cannot run keeps the cost search's tile on igemm_dma_kernel when the request was a tuned hint
             // (tables are keyed by geometry, not by epilogue) and fails when it was forced.
             const int KT = d.K / 32;
@@ -464,6 +479,40 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
             }
             ALDM_CHECK(!g_force_bm, "aldm_igemm: the operand-stationary DMA kernel cannot run this launch (K = %d, %d stages, %d parts)",
                        d.K, os_nst, d.split_parts);
+            f_st = 0;
+        }
+        if (f_st >= 400) {
+            // stages 400 + 10 * w8 + depth: the halo-patch kernel (3x3 stride-1 convolutions; depth = weight-ring stages, w8 = 1: the
+            // 128-row tile on 8 waves).  Split-K must cut between channel blocks.  As above: a hinted launch it cannot run falls
+            // back to the cost search, a forced one fails.
+            const int hb = f_st - 400, nstb = hb % 10, w8 = hb / 10;
+            const int bm = f_bm ? f_bm : 256, bn = f_bn ? f_bn : 128;
+            const int wm = bm == 256 ? 4 : (w8 ? 4 : 2);
+            const int nch = dma_halo_chunks(p, bm);
+            const int maxch = nch > 0 && !geglu && !qkv ? igemm_dma_halo_maxch(bm, bn, nstb, wm, d.split_parts, nch) : 0;
+            const int cpb = p.Cin / 32;
+            int sp = f_sp > 0 ? f_sp : 1;
+            if (sp > 1 && (!can_split || !have_ws || cpb % sp != 0 || d.ws_floats < (int64_t)sp * p.M * d.N)) sp = 0;
+            if (maxch > 0 && sp > 0) {
+                BM = bm;
+                BN = bn;
+                p.tiles_m = p.M / BM;
+                p.tiles_n = cdiv(d.N, BN);
+                p.splits = sp;
+                p.kt_per_split = 9 * (cpb / sp);
+                p.kgroups = 1;
+                p.bx = 1;
+                p.pre = pre;
+                p.dma = 1;
+                p.nst = nstb;
+                p.ws = 4;
+                p.ws_blocks = wm;
+                p.os_rows = maxch;
+                return 0;
+            }
+            ALDM_CHECK(!g_force_bm, "aldm_igemm: the halo-patch DMA kernel cannot run this launch (tile %dx%d, %d stages, %d waves, "
+                       "%d parts, %d splits; 3x3 / stride 1 / pad 1, W a power of two dividing the tile, OH*OW %% tile == 0)", bm, bn,
+                       nstb, 2 * wm, d.split_parts, f_sp);
             f_st = 0;
         }
         if (f_st >= 200) {
@@ -668,6 +717,7 @@ extern "C" int aldm_igemm_plan_stages(const aldm_igemm_desc* dd) {
     IgemmK p;
     int BM, BN;
     if (igemm_prepare(dd, p, BM, BN)) return -1;
+    if (p.dma && p.ws == 4) return 400 + (BM == 128 && p.ws_blocks == 4 ? 10 : 0) + p.nst;
     return p.dma ? p.nst + 100 * p.ws : 0;
 }
 
@@ -710,7 +760,9 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
                    "aldm_igemm: aldm_debug_drop_product is set: force the classic DMA-fed 64x128 tile with 2 stages and 3-part images "
                    "(got dma=%d form=%d tile %dx%d, %d stages, %d parts) or clear the switch", p.dma, p.ws, BM, BN, p.nst, d.split_parts);
 #endif
-    if (p.dma && p.ws == 3) {
+    if (p.dma && p.ws == 4) {
+        rc = igemm_launch_dma_halo(BM, BN, p.nst, p.ws_blocks, d.split_parts, p.os_rows, grid, st, p);
+    } else if (p.dma && p.ws == 3) {
         rc = igemm_launch_dma_os(d.K / 32, p.nst, d.split_parts, grid, st, p);
     } else if (p.dma && p.ws == 2) {
         rc = igemm_launch_dma_lw(BM, BN, p.nst, d.split_parts, grid, st, p);

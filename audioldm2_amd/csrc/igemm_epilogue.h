@@ -24,7 +24,8 @@ struct IgemmK {
     int dma;                   // 1: DMA-fed kernel over a pre-split A image (d.a_split)
     int nst;                   // DMA kernel: LDS ring depth of the chosen instantiation
     int ws;                    // 1: the persistent wave-specialised DMA kernel (igemm_dma_ws.h), ws_blocks blocks; 2: loader waves
-                               // (igemm_dma_lw.h); 3: the operand-stationary kernel (igemm_dma_os.h)
+                               // (igemm_dma_lw.h); 3: the operand-stationary kernel (igemm_dma_os.h); 4: the halo-patch kernel
+                               // (igemm_dma_halo.h: ws_blocks = WM, os_rows = MAXCH of the instantiation)
     int ws_blocks;
     int os_rows;               // operand-stationary kernel: rows per block (a multiple of 32)
 };

@@ -677,3 +677,106 @@ def test_dma_os_refuses_what_it_cannot_run_and_hints_fall_back(ops):
             tab[d_keys[0]] = had
     assert rel_err(y0, y1) < OS_TOL
     assert rel_err(y1, xs.float().double().cpu() @ w.double().t()) < gemm_tol()
+
+
+# ---- the halo-patch 3x3 convolution kernel (csrc/igemm_dma_halo.h) -------------------------------------------
+# (tile, stages code 400 + 10 * w8 + weight-ring depth) per mode: every instantiation of igemm_dma_halo.hip
+_HALO = {"bf16x6": [(256, 128, 402), (128, 128, 403), (128, 128, 404), (128, 128, 402), (128, 128, 412), (128, 128, 413)],
+         "bf16x3": [(256, 128, 402), (256, 128, 403), (128, 128, 403), (128, 128, 404), (128, 128, 413)]}
+
+
+def _halo_case(ops, bm, bn, st, B, C, N, H, W, splits=1, epilogue=True):
+    """conv3x3(x) (+ bias, timestep row bias, SiLU, residual) on the halo kernel against fp64 and against igemm_dma_kernel."""
+    x = torch.randn(B, C, H, W, generator=g(1))
+    w = torch.randn(N, C, 3, 3, generator=g(2)) / math.sqrt(C * 9)
+    b = torch.randn(N, generator=g(3))
+    emb = torch.randn(B, N, generator=g(4))
+    res = torch.randn(B, N, H, W, generator=g(5))
+    conv = F.conv2d(x, w, b, padding=1)
+    ref = F.silu(conv + emb[:, :, None, None]) + res if epilogue else conv
+    pw = ops.pack_conv(w, b)
+    xs = ops.split_rows(cl(x))
+    kw = dict(rowbias=emb.cuda(), act=ops.ACT_SILU, res=cl(res)) if epilogue else {}
+    y_classic = ops.conv(xs, pw, pad=(1, 1), **kw)
+    ops.igemm_force(bm, bn, splits, 0, st)
+    try:
+        y, s = ops.conv(xs, pw, pad=(1, 1), split_out="also", **kw)
+        y2 = ops.conv(xs, pw, pad=(1, 1), **kw)
+    finally:
+        ops.igemm_force(0, 0, 0)
+    tol = fused_tol() if epilogue else gemm_tol()
+    assert rel_err(uncl(y), ref) < tol
+    assert torch.equal(y, y2), "must be bitwise reproducible"
+    assert_split_equals(ops, s, y)
+    # the same products in another summation order (channel block outer, tap inner): fp32 rounding apart
+    assert rel_err(y, y_classic) < (2e-6 if exact_split(ops) else 1e-5)
+
+
+@pytest.mark.parametrize("mode,bm,bn,st", [(m, *t) for m, ts in _HALO.items() for t in ts])
+def test_dma_halo_every_instantiation(mode, bm, bn, st):
+    """Every instantiation on the UNet's level-0 geometry in small (W = 16, two images, 128 -> 192 channels: a ragged second
+    column tile), full epilogue, split-image second output.  (The 4-deep weight ring of the 4-wave 128-row tile leaves 7 patch-piece
+    slots per channel block: 28 pieces, enough for W <= 8 with 3-part images — that instantiation runs the level-1 geometry.)"""
+    from audioldm2_amd import ops
+    prev = ops.set_mma(mode)
+    try:
+        if st == 404 and mode == "bf16x6":
+            _halo_case(ops, bm, bn, st, B=2, C=128, N=192, H=64, W=8)
+        else:
+            _halo_case(ops, bm, bn, st, B=2, C=128, N=192, H=32, W=16)
+    finally:
+        ops.set_mma(prev)
+
+
+@pytest.mark.parametrize("W,H,bm,st", [(16, 256, 256, 402), (8, 128, 256, 402), (8, 128, 128, 403), (4, 64, 256, 402), (4, 64, 128, 403),
+                                       (2, 64, 128, 403), (32, 16, 128, 412), (64, 8, 128, 412), (16, 16, 256, 402), (16, 8, 128, 403)])
+def test_dma_halo_image_widths(ops, W, H, bm, st):
+    """Every image width the sampling path has (UNet levels 16 / 8 / 4 / 2, VAE decoder 16 / 32 / 64), tiles at the top and bottom
+    image border and in the middle, a tile that is a whole image (zero rows on both sides), a half-used last patch chunk (W = 4)."""
+    if ops.split_parts() == 2 and st == 402 and bm == 128:
+        st = 403
+    if ops.split_parts() == 2 and st == 412:
+        st = 413
+    _halo_case(ops, bm, 128, st, B=2, C=64, N=128, H=H, W=W, epilogue=False)
+
+
+@pytest.mark.parametrize("splits", [2, 3])
+def test_dma_halo_split_k_cuts_between_channel_blocks(ops, splits):
+    """Split-K of the halo kernel hands whole 32-channel blocks (9 k-tiles each) to every split: C = 192 = 6 blocks -> 3 + 3 /
+    2 + 2 + 2; the workspace reduce applies the epilogue."""
+    _halo_case(ops, 128, 128, 403, B=1, C=192, N=128, H=32, W=8, splits=splits)
+
+
+def test_dma_halo_refuses_what_it_cannot_run_and_hints_fall_back(ops):
+    """FORCED onto a launch outside its domain (stride 2; a 1x1 conv; an image whose rows do not tile) the halo kernel fails
+    loudly; as a tuned HINT (tables are keyed by geometry) the same request falls back to aldm_igemm's own choice."""
+    x = torch.randn(1, 64, 24, 16, generator=g(1))          # OH * OW = 384: not a multiple of the 256-row tile
+    w = torch.randn(64, 64, 3, 3, generator=g(2)) / math.sqrt(64 * 9)
+    pw = ops.pack_conv(w, None)
+    xs = ops.split_rows(cl(x))
+    ops.igemm_force(256, 128, 1, 0, 402)
+    try:
+        with pytest.raises(RuntimeError, match="halo-patch"):
+            ops.conv(xs, pw, pad=(1, 1))
+        with pytest.raises(RuntimeError, match="halo-patch"):
+            ops.conv(xs, pw, stride=(2, 2), pad=(1, 1))
+    finally:
+        ops.igemm_force(0, 0, 0)
+    tab = ops._tuned_table("dma2" if ops.split_parts() == 2 else "dma")
+    keys = []
+    ops.TUNE_LOG = keys
+    try:
+        y0 = ops.conv(xs, pw, pad=(1, 1))
+    finally:
+        ops.TUNE_LOG = None
+    had = tab.get(keys[0])
+    tab[keys[0]] = [256, 128, 1, 402]
+    try:
+        y1 = ops.conv(xs, pw, pad=(1, 1))
+    finally:
+        if had is None:
+            del tab[keys[0]]
+        else:
+            tab[keys[0]] = had
+    assert torch.equal(y0, y1) or rel_err(y0, y1) < 2e-6
+    assert rel_err(uncl(y1), F.conv2d(x, w, padding=1)) < gemm_tol()
