@@ -32,6 +32,14 @@
 #pragma once
 #include "igemm_dma.h"
 
+#ifndef ALDM_HALO_ABLATE
+#define ALDM_HALO_ABLATE 0   // timing-only builds (tools/gpu/build_variant.sh): 1 every patch piece is a dummy (no A traffic after the
+                             // prologue), 2 weight pieces read the zero page, 32 fragment addresses are not recomputed per tap, 64 every weight k-tile is tile 0
+                             // (REAL operand bits from a cache-resident address: 1 and 2 feed ZEROS to the matrix pipe, which lowers its power
+                             // draw and raises the clock — they overstate what the feed costs), 128 every patch is channel block cb0's;
+                             // ALDM_DMA_ABLATE's 4 (no MFMA), 8 (no fragment reads), 16 (no epilogue) apply as in igemm_dma.h
+#endif
+
 namespace aldm {
 
 constexpr int halo_lds_slots(int BN, int NSTB, int NP, int MAXCH) {
@@ -99,39 +107,59 @@ void igemm_dma_halo_kernel(const IgemmK p) {
     using lptr_t = __attribute__((address_space(3))) void*;
 
     // ---- patch pieces ---------------------------------------------------------------------------------------------------
-    // piece `id` of the patch of relative channel block ci (live: that block exists and the slot is a real one)
-    auto issue_patch_piece = [&](int id, int ci, bool live) {
+    // Source / destination of piece `id` of the patch of relative channel block ci (live: that block exists and the slot is a real
+    // one).  Branch free (both candidates are computed, then selected: it runs among the MFMAs in front of the barrier): a wave-
+    // uniform 64-bit base — the patch's first pixel, channel block ci — plus a 32-bit lane offset; lanes outside the image, beyond
+    // the patch or of a dummy piece read the zero page, and a dummy piece lands in the zero region.
+    const int64_t patch_pix0 = (int64_t)(img * d.H + r0 - 1) * W;   // (row r0 - 1 may lie outside the image: never dereferenced then)
+    const char* patch_base0 = abase + (patch_pix0 * rowbytes + (int64_t)cb0 * PB);
+    const unsigned rowbytes32 = (unsigned)rowbytes;                  // host: the patch spans < 2^31 bytes
+    struct Piece {
+        const char* src;
+        int dst;   // LDS slot (wave uniform)
+    };
+    auto prep_patch_piece = [&](int id, int ci, bool live) -> Piece {
         const int j = id / NP, q = id - j * NP;
-        const bool valid = live && j < NCH;
-        const int px = j * 16 + (lane >> 2);
+        const bool valid = live & (j < NCH);   // (& not &&: no short-circuit branch — a control-flow join in the loop makes hipcc
+        const int px = j * 16 + (lane >> 2);   //  wait for the fresh fragment reads before the first MFMA, see igemm_dma.h)
         const int irow = r0 - 1 + (px >> lgW);
-        const bool ok = valid && px < PP && (unsigned)irow < (unsigned)d.H;
-        const int64_t pix = (int64_t)(img * d.H + irow) * W + (px & (W - 1));
-        const char* src = ok ? abase + (pix * rowbytes + (int64_t)(cb0 + ci) * PB + q * 64 + lane_off) : zero + lane_off;
-        u32x4* dst = valid ? &smem[(ci & 1) * PATCH + (j * NP + q) * 64] : &smem[Z0];
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        const bool ok = valid & (px < PP) & ((unsigned)irow < (unsigned)d.H);
+        const unsigned off = (unsigned)px * rowbytes32 + (unsigned)(q * 64 + lane_off);
+        const char* real = patch_base0 + (int64_t)((ALDM_HALO_ABLATE & 128) ? 0 : ci) * PB + off;
+        const char* zsrc = zero + lane_off;
+        Piece pc;
+        pc.src = ok ? real : zsrc;
+        const int dreal = (ci & 1) * PATCH + (j * NP + q) * 64;
+        pc.dst = valid ? dreal : Z0;
+        return pc;
+    };
+    auto issue_piece = [&](const Piece& pc) {
+        __builtin_amdgcn_global_load_lds((gptr_t)pc.src, (lptr_t)&smem[pc.dst], 16, 0, 0);
     };
     int av_s = 0, av_c = 1;   // next patch-piece slot: slot av_s of the patch of relative channel block av_c
-    auto issue_a = [&]() { issue_patch_piece(av_s * NW + wave, av_c, av_s < ATILES && av_c < ncb); };
+    auto prep_a = [&]() {
+        return prep_patch_piece(av_s * NW + wave, av_c, (ALDM_HALO_ABLATE & 1) ? false : (av_s < ATILES) & (av_c < ncb));
+    };
     auto advance_a = [&]() {
-        if (++av_s == 9) {
-            av_s = 0;
-            ++av_c;
-        }
+        const bool wrap = av_s == 8;
+        av_s = wrap ? 0 : av_s + 1;
+        av_c += wrap ? 1 : 0;
     };
 
     // ---- weight pieces: chunk c = wave*NB + j -> (slot row = octet*NP + part, 64-column half) ---------------------------------
-    const char* b_ptr[NB];
-    int64_t b_tile[NB];   // bytes between consecutive weight k-tiles (0 for out-of-range columns -> zero page)
+    // k-tile (cb, tap) is weight tile tap * cpb + cb.  A wave-uniform tile pointer advances by scalar adds; the lane part is
+    // constant.  Columns beyond Npad (a 128-column tile over N = 192) re-read the last real column: finite values whose
+    // accumulators the epilogue never stores.
+    unsigned b_off[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int c = wave * NB + j;
         const int srow = c / (BN / 64), half = c % (BN / 64);
-        const int col = n0 + half * 64 + lane;
-        const bool ok = col < p.Npad;
-        b_tile[j] = ok ? (int64_t)4 * NP * p.Npad * 16 : 0;
-        b_ptr[j] = ok ? wbase + (((int64_t)cb0 * 4 * NP + srow) * p.Npad + col) * 16 : zero;   // tile (tap 0, cb0)
+        const int col = min(n0 + half * 64 + lane, p.Npad - 1);
+        b_off[j] = (unsigned)((srow * p.Npad + col) * 16);
     }
+    const int64_t b_tile = (int64_t)4 * NP * p.Npad * 16;       // bytes of one weight k-tile
+    const char* b_base = wbase + (int64_t)cb0 * b_tile;        // tile (tap 0, cb0)
     int bt_tap = 0;   // tap of the next weight k-tile to issue
     auto issue_b = [&](int st) {
         u32x4* sb = &smem[B0 + st * BSTG];
@@ -139,14 +167,14 @@ void igemm_dma_halo_kernel(const IgemmK p) {
         for (int j = 0; j < NB; ++j) {
             const int c = wave * NB + j;
             const int srow = c / (BN / 64), half = c % (BN / 64);
-            __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[j], (lptr_t)(sb + srow * BN + half * 64), 16, 0, 0);
+            const char* src = (ALDM_HALO_ABLATE & 2) ? zero + lane * 16 : b_base + b_off[j];
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + srow * BN + half * 64), 16, 0, 0);
         }
     };
     auto advance_b = [&]() {   // tap inner: + cpb tiles; after tap 8 the next channel block's tap 0: + 1 - 8 cpb tiles
-        const int64_t step = (++bt_tap == 9) ? 1 - (int64_t)8 * cpb : cpb;
-        if (bt_tap == 9) bt_tap = 0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) b_ptr[j] += b_tile[j] * step;
+        const bool wrap = bt_tap == 8;
+        bt_tap = wrap ? 0 : bt_tap + 1;
+        if (!(ALDM_HALO_ABLATE & 64)) b_base += b_tile * (wrap ? 1 - 8 * cpb : cpb);
     };
 
     // ---- fragments ------------------------------------------------------------------------------------------------------
@@ -157,26 +185,31 @@ void igemm_dma_halo_kernel(const IgemmK p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) pt[i] = (wm * MT + i) * 32 + l31;
     unsigned aaddr[MT];    // LDS byte address of this lane's k-octet lh fragment (step 0) for the tile being read; step 1: ^ 32
-    int c_kh = 0, c_kw = 0, c_buf = 0;   // tap / patch buffer of the tile being read
-    auto set_aaddr = [&]() {
+    unsigned aaddr_n[MT];  // ... for the tile after it (computed among the MFMAs in front of the barrier)
+    int c_kh = 0, c_kw = 0, c_buf = 0;   // tap / patch buffer of the tile `aaddr_n` was last computed for
+    auto set_aaddr_n = [&]() {   // branch free: both candidates, then a select
         const int toff = c_kh * W + c_kw - 1;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int pp = pt[i] + toff;
             const int cc = (pt[i] & (W - 1)) + c_kw - 1;
             const unsigned off = (unsigned)(pp >> 4) * (NP * 1024) + (unsigned)(pp & 15) * 64 + (unsigned)((((pp >> 2) & 3) ^ lh) << 4);
-            aaddr[i] = (unsigned)cc < (unsigned)W ? (unsigned)(c_buf * PATCH * 16) + off : (unsigned)(Z0 * 16 + lh * 16);
+            const unsigned real = (unsigned)(c_buf * PATCH * 16) + off;
+            const unsigned zslot = (unsigned)(Z0 * 16 + lh * 16);
+            aaddr_n[i] = (unsigned)cc < (unsigned)W ? real : zslot;
         }
     };
-    auto advance_tap = [&]() {
-        if (++c_kw == 3) {
-            c_kw = 0;
-            if (++c_kh == 3) {
-                c_kh = 0;
-                c_buf ^= 1;
-            }
-        }
-        set_aaddr();
+    auto next_tap = [&]() {
+        const bool w1 = c_kw == 2;
+        c_kw = w1 ? 0 : c_kw + 1;
+        const bool w2 = w1 && c_kh == 2;
+        c_kh = w2 ? 0 : (w1 ? c_kh + 1 : c_kh);
+        c_buf ^= w2 ? 1 : 0;
+        if (!(ALDM_HALO_ABLATE & 32)) set_aaddr_n();
+    };
+    auto take_aaddr = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) aaddr[i] = aaddr_n[i];
     };
     const char* lds = reinterpret_cast<const char*>(smem);
     auto read_frags = [&](Frag& f, int st, int step) {
@@ -241,8 +274,8 @@ void igemm_dma_halo_kernel(const IgemmK p) {
     // ---- prologue: the zero region, the whole patch of the first channel block, slot 0 of the second, NSTB weight tiles ----------
     if (wave < NP)
         __builtin_amdgcn_global_load_lds((gptr_t)(zero + lane * 16), (lptr_t)&smem[Z0 + wave * 64], 16, 0, 0);
-    for (int id = wave; id < NCH * NP; id += NW) issue_patch_piece(id, 0, true);
-    issue_a();
+    for (int id = wave; id < NCH * NP; id += NW) issue_piece(prep_patch_piece(id, 0, true));
+    issue_piece(prep_a());
     advance_a();
 #pragma unroll
     for (int s = 0; s < NSTB; ++s)
@@ -252,7 +285,8 @@ void igemm_dma_halo_kernel(const IgemmK p) {
         }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    set_aaddr();
+    set_aaddr_n();
+    take_aaddr();
     Frag f0, f1;
 #if ALDM_DMA_ABLATE & 8
     for (int q = 0; q < NP; ++q) {
@@ -268,11 +302,17 @@ void igemm_dma_halo_kernel(const IgemmK p) {
         constexpr bool ST = decltype(steady)::value;
         constexpr int NMF = NPROD * MT * NT, NRD = NP * (MT + NT);
         read_frags(f1, st, 1);
+        // what the second half needs right behind the barrier is computed here, in the shadow of k-step 0's MFMAs: the next
+        // tile's fragment addresses and the patch piece's source pointer
+        next_tap();
+        Piece pc;
+        if constexpr (ST) pc = prep_a();
         mma_frags(f0);
 #pragma unroll
-        for (int q = 0; q < NMF; ++q) {   // one fragment read behind each of the first MFMAs
+        for (int q = 0; q < NMF; ++q) {   // one fragment read and a few address instructions behind each of the first MFMAs
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (q < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int st1 = st + 1 == NSTB ? 0 : st + 1;
@@ -282,9 +322,9 @@ void igemm_dma_halo_kernel(const IgemmK p) {
         __builtin_amdgcn_s_barrier();
         if constexpr (ST) {
             issue_b(st);
-            issue_a();
+            issue_piece(pc);
         }
-        advance_tap();
+        take_aaddr();
         read_frags(f0, st1, 0);
         mma_frags(f1);
 #pragma unroll

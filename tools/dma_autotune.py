@@ -32,9 +32,58 @@ WS_CFGS = {3: [(64, 128, 102), (64, 128, 103), (64, 64, 102)],
            2: [(64, 128, 102), (64, 128, 103), (128, 64, 102), (64, 64, 103), (64, 64, 104)]}
 # operand-stationary form for short K (csrc/igemm_dma_os.h): "tile" 32x128, stages = 300 + ring depth; K = 256 / 384 1x1 launches only
 OS_CFGS = {3: [(32, 128, 302), (32, 128, 303)], 2: [(32, 128, 302), (32, 128, 303), (32, 128, 304)]}
+# halo-patch form for 3x3 / stride-1 / pad-1 convolutions (csrc/igemm_dma_halo.h): stages = 400 + 10 * w8 + weight-ring depth
+HALO_CFGS = {3: [(256, 128, 402), (128, 128, 402), (128, 128, 403), (128, 128, 404), (128, 128, 412), (128, 128, 413)],
+             2: [(256, 128, 402), (256, 128, 403), (128, 128, 403), (128, 128, 404), (128, 128, 413)]}
 SPLITS = [1, 2, 3, 4, 6, 8]
 PARTS = 2 if os.environ.get("ALDM_MMA") == "bf16x3" else 3
 SUFFIX = ",dma2" if PARTS == 2 else ",dma"
+
+
+def halo_geometry(key):
+    f = dict(zip(ops._TUNE_FIELDS, (int(t) for t in key.split(",")[:len(ops._TUNE_FIELDS)])))
+    return (f["KH"], f["KW"], f["SH"], f["SW"], f["PH"], f["PW"], f["DH"], f["DW"], f["up_h"], f["up_w"]) == (3, 3, 1, 1, 1, 1, 1, 1, 1, 1) \
+        and f["out_mul"] == 0 and f["W"] & (f["W"] - 1) == 0 and (f["H"] * f["W"]) % 128 == 0 and f["C1"] % 32 == 0 and f["C2"] == 0
+
+
+def tune_halo(key, lib, entry):
+    """The geometry's current table entry (or the cost model's choice) against every halo form it can run."""
+    d, keep, M, N, K = at.make_desc(key[:-len(SUFFIX)])
+    npix = d.B * d.H * d.W
+    x = torch.randn(npix, d.C1, device="cuda")
+    img = ops.split_rows(x)
+    d.a_split = img.data_ptr()
+    d.split_parts = PARTS
+    if PARTS == 2:
+        w2 = torch.empty(lib.aldm_split_bytes_parts(K, N, 2) // 4, device="cuda", dtype=torch.int32)
+        keep.append(w2)
+        L.check(lib.aldm_pack_split_bf16_parts(d.w, w2.data_ptr(), K, N, 2, torch.cuda.current_stream().cuda_stream), "split2")
+        d.w_split = w2.data_ptr()
+    d.x1 = None
+    d.pre_scale = d.pre_shift = None
+    d.pre_act = 0
+    flops = 2.0 * M * N * K
+    reps = 3 if flops > 2e10 else 8
+    d.hint_bm = d.hint_bn = d.hint_splits = d.hint_stages = 0
+    if entry:
+        d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = entry[:4]
+    t_cur = at.time_launch(lib, d, reps)
+    if t_cur is None:
+        return None, None, flops, (M, N, K)
+    best = (t_cur, None)
+    cpb = d.C1 // 32
+    for bm, bn, st in HALO_CFGS[PARTS]:
+        for sp in (1, 2, 3, 4, 6):
+            if sp > 1 and (cpb % sp or N % 4 or M * N * sp > (1 << 26)):
+                continue
+            d.hint_bm, d.hint_bn, d.hint_splits, d.hint_stages = bm, bn, sp, st
+            if lib.aldm_igemm_plan_stages(C.byref(d)) != st:
+                continue
+            ops._workspace(lib, d, torch.device("cuda", torch.cuda.current_device()))
+            t = at.time_launch(lib, d, reps)
+            if t is not None and t < best[0]:
+                best = (t, [bm, bn, sp, st])
+    return t_cur, best, flops, (M, N, K)
 
 
 def tune(key, lib):
@@ -126,11 +175,29 @@ def main():
     min_count = int(os.environ.get("DMA_TUNE_MIN_COUNT", "0"))
     known = set(entries)
     only_os = os.environ.get("DMA_TUNE_ONLY_OS", "0") == "1"   # re-tune (only) the geometries the operand-stationary kernel can run
+    only_halo = os.environ.get("DMA_TUNE_ONLY_HALO", "0") == "1"   # ... the halo-patch kernel can run, against their current entries
 
     def os_geometry(key):
         f = key.split(",")
         return f[8] == "1" and f[9] == "1" and f[3] in ("256", "384") and f[4] == "0"
     for key, n in sorted(counts.items()):
+        if only_halo:
+            if not halo_geometry(key) or n < min_count:
+                continue
+            t_cur, best, flops, mnk = tune_halo(key, lib, entries.get(key))
+            if t_cur is None:
+                continue
+            total += t_cur * n
+            line = f"M{mnk[0]} N{mnk[1]} K{mnk[2]} n={n} current {entries.get(key, ['auto'])[:4]} {t_cur:.1f}us"
+            if best[1] and best[0] < 0.98 * t_cur:
+                auto_us = entries[key][5] if key in entries and len(entries[key]) > 5 else round(t_cur, 1)
+                entries[key] = best[1] + [round(best[0], 1), auto_us]
+                saved += (t_cur - best[0]) * n
+                line += f" -> halo {best[1]} {best[0]:.1f}us {flops / best[0] / 1e6:.1f} TF ({100 * (best[0] / t_cur - 1):+.0f} %)"
+            else:
+                line += " -> kept"
+            print(line, flush=True)
+            continue
         if only_os:
             if not os_geometry(key) or n < min_count:
                 continue
