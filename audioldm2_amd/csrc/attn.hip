@@ -663,7 +663,16 @@ __global__ __launch_bounds__(256) void attention_d32_pipe_kernel(
 template <int N, int S>
 constexpr int item_slot(int k, int base) { return base + (k * S) / N; }
 
-template <int QT, int NP>
+// LDSKV (round 6, aldm_attention_sched 3): the four waves of a block need the SAME K / V^T tiles — without it each of them streams its
+// own copy of every tile from L2 (805 MB of L2 -> register traffic per 16 x 8 x 1024 x 1024 launch for 50 MB of distinct data; the
+// ablation of profiles/r05_attn_ablate.txt prices that at 28 of the launch's 95 us).  With it a tile crosses L2 -> LDS ONCE per
+// block: its 4 NP fragment sets (K / V^T x k-step x part, 1 KB each: exactly the 64-lane register image the MFMAs consume) are
+// LDS-DMA pieces dealt to the four waves (global_load_lds_dwordx4: the lanes fetch what load_k / load_v would have fetched, the
+// piece lands lane-contiguous), into an NST-deep ring of tiles; load_k / load_v become conflict-free ds_read_b128 at the same
+// places of the schedule.  One s_barrier per key tile at the top of the body: behind it the pieces of tile j + 2 (issued NST - 3
+// tiles earlier, waited for with a counted vmcnt) are visible to every wave and the stage of tile j - 1 is free for tile
+// j + NST - 1.  Same arithmetic in the same order: bit-identical results.  Needs every wave of the block live (Lq % (128 QT) == 0).
+template <int QT, int NP, bool LDSKV = false>
 __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     const float* __restrict__ q, const void* __restrict__ k_img, const void* __restrict__ vt_img, float* __restrict__ out,
     int Lq, int Lk, int ldq, int heads, int ldo, float scale, void* __restrict__ out_split, int split_c, int parts) {
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     const int h = blockIdx.y;
     const int b = blockIdx.z;
     const int q0 = (blockIdx.x * 4 + wave) * 32 * QT;
-    if (q0 >= Lq) return;  // wave-uniform
+    if (!LDSKV && q0 >= Lq) return;  // wave-uniform (LDSKV: the host launches whole blocks only — every wave joins the barriers)
 
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int PA_[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
@@ -720,21 +729,61 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     f32x16 oT[QT];
     float m_run[QT], l_run[QT], alpha[QT], m_new[QT], tmax[QT], psum[QT];
 
+    // LDSKV: ring of NST tiles x (2 NP K fragment sets + 2 NP V^T fragment sets) x 64 lanes x 16 bytes
+    constexpr int NST = 6, TILE_SLOTS = 4 * NP * 64, PPW = NP;   // pieces per wave and tile: 4 NP / 4 waves
+    __shared__ u32x4 kv_lds[LDSKV ? NST * TILE_SLOTS : 1];
+    auto dma_tile = [&](int tile) {   // this wave's PPW pieces of `tile` (past the end: the last tile again, keeps vmcnt uniform)
+        using gptr_t = const __attribute__((address_space(1))) void*;
+        using lptr_t = __attribute__((address_space(3))) void*;
+        const int tc = min(tile, t_last);
+        u32x4* stg = &kv_lds[(tile % NST) * TILE_SLOTS];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pi = wave * PPW + i;             // 0 .. 4 NP - 1: (K | V, k-step s, part p)
+            const int isv = pi / (2 * NP), sp = pi - isv * (2 * NP), ks = sp / NP, pp = sp - ks * NP;
+            const char* ksrc = kimg + ((int64_t)tc * 32 * heads * (64 * NP) + koff + 16 * ks + 64 * pp);
+            const char* vsrc = vimg + ((int64_t)tc * (NP * 2048) + voff + 32 * ks + 2048 * pp);
+            __builtin_amdgcn_global_load_lds((gptr_t)(isv ? vsrc : ksrc), (lptr_t)(stg + pi * 64), 16, 0, 0);
+        }
+    };
     auto load_k = [&](auto pc, int tile) {
         constexpr int P = decltype(pc)::value;
-        const int sk = __builtin_amdgcn_readfirstlane(min(tile, t_last) * 32 * heads * (64 * NP));
+        if constexpr (LDSKV) {
+            const u32x4* stg = &kv_lds[(tile % NST) * TILE_SLOTS + lane];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Kr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * s + 64 * p, sk, 0);
+                for (int p = 0; p < NP; ++p) Kr[P][s][p] = stg[(s * NP + p) * 64];
+        } else {
+            const int sk = __builtin_amdgcn_readfirstlane(min(tile, t_last) * 32 * heads * (64 * NP));
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) Kr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rk, koff + 16 * s + 64 * p, sk, 0);
+        }
     };
     auto load_v = [&](auto pc, int tile) {
         constexpr int P = decltype(pc)::value;
-        const int sv = __builtin_amdgcn_readfirstlane(min(tile, t_last) * (NP * 2048));
+        if constexpr (LDSKV) {
+            const u32x4* stg = &kv_lds[(tile % NST) * TILE_SLOTS + 2 * NP * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Vr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff + 32 * s + 2048 * p, sv, 0);
+                for (int p = 0; p < NP; ++p) Vr[P][s][p] = stg[(s * NP + p) * 64];
+        } else {
+            const int sv = __builtin_amdgcn_readfirstlane(min(tile, t_last) * (NP * 2048));
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) Vr[P][s][p] = __builtin_amdgcn_raw_buffer_load_b128(rv, voff + 32 * s + 2048 * p, sv, 0);
+        }
+    };
+    // LDSKV, top of the body of tile j: my pieces of tile j + 2 have landed (the PPW (NST - 4) pieces of tiles j + 3 .. j + NST - 2
+    // may stay in flight), my reads of tile j - 1's stage are complete; behind the barrier that holds for every wave
+    auto ring_sync = [&]() {
+        constexpr int N = PPW * (NST - 4);
+        __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
     };
 
     // ---- work items (each <= ~11 VALU instructions) ----
@@ -846,10 +895,12 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
 
     auto body = [&](auto pc, int j) {
         constexpr int P = decltype(pc)::value, Q = 1 - P;
+        if constexpr (LDSKV) ring_sync();
         // phase 1
         static_for<0, NMF>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             mfma_qk(pc, ic);
+            if constexpr (LDSKV && i == 1) dma_tile(j + NST - 1);   // the stage of tile j - 1 is free behind the barrier
             static_for<0, N1>([&](auto kc) {
                 if constexpr (item_slot<N1, NMF>(decltype(kc)::value, 0) == i) run_item1(pc, kc, j);
             });
@@ -877,6 +928,11 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     // prologue: tile 0 (parity 0): its Q.K^T and softmax, nothing to overlap with yet; K_1, V_0 in flight behind K_0
+    if constexpr (LDSKV) {   // tiles 0 .. NST - 1 fill the ring (the body of tile j adds tile j + NST - 1); 0 .. 2 are read below
+#pragma unroll
+        for (int tt = 0; tt < NST; ++tt) dma_tile(tt);
+        ring_sync();
+    }
     load_k(P0{}, 0);
     load_k(P1{}, 1);
     load_v(P0{}, 0);
@@ -1485,7 +1541,20 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
             if (qt2) ALDM_ATTN_PRE2(attention_d32_presplit3_kernel, 2, 3);
             else ALDM_ATTN_PRE2(attention_d32_presplit3_kernel, 1, 3);
         }
-    } else if (sched == 1) {
+    } else if (sched == 3 && Lq % (qt2 ? 256 : 128) == 0) {
+        // K / V^T through LDS once per block (whole blocks only: every wave joins the per-tile barrier)
+#define ALDM_ATTN_PRE4(Q_, P_)                                                                                               \
+    hipLaunchKernelGGL((attention_d32_presplit2_kernel<Q_, P_, true>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk, ldq, \
+                       heads, ldo, scale, out_split, split_c, parts)
+        if (parts == 2) {
+            if (qt2) ALDM_ATTN_PRE4(2, 2);
+            else ALDM_ATTN_PRE4(1, 2);
+        } else {
+            if (qt2) ALDM_ATTN_PRE4(2, 3);
+            else ALDM_ATTN_PRE4(1, 3);
+        }
+#undef ALDM_ATTN_PRE4
+    } else if (sched == 1 || sched == 3) {
         if (parts == 2) {
             if (qt2) ALDM_ATTN_PRE2(attention_d32_presplit2_kernel, 2, 2);
             else ALDM_ATTN_PRE2(attention_d32_presplit2_kernel, 1, 2);

@@ -780,3 +780,29 @@ def test_dma_halo_refuses_what_it_cannot_run_and_hints_fall_back(ops):
             tab[keys[0]] = had
     assert torch.equal(y0, y1) or rel_err(y0, y1) < 2e-6
     assert rel_err(uncl(y1), F.conv2d(x, w, padding=1)) < gemm_tol()
+
+
+@pytest.mark.parametrize("B,L,heads", [(16, 1024, 8), (16, 256, 12), (2, 128, 2), (2, 512, 4), (1, 256, 2), (3, 64, 20), (16, 128, 8),
+                                       (2, 384, 2)])
+def test_presplit_attention_with_kv_through_lds_is_bitwise_the_default(ops, B, L, heads):
+    """aldm_attention_sched(3): the K / V^T tiles of a (sample, head) cross L2 -> LDS once per block instead of once per wave (an
+    NST-deep ring of LDS-DMA pieces, one s_barrier per key tile); the arithmetic and its order are the default kernel's, so the
+    outputs are BIT-identical — at one, two, three and many key tiles, 32 and 64 queries per wave, and on launches with partial
+    blocks (64 / 128 / 384 queries: those stay on the default kernel).  In one process, through the setter."""
+    C = heads * 32
+    q, k, v = (torch.randn(B, L, C, generator=g(i)) for i in (1, 2, 3))
+    (qi, kimg, vtimg), qkv = _qkv_images(ops, q, k, v, heads)
+    prev = ops.attention_sched(1)
+    try:
+        a1 = ops.attention_presplit(qi, kimg, vtimg, heads)
+        assert ops.attention_sched(3) == 1
+        a3 = ops.attention_presplit(qi, kimg, vtimg, heads)
+        a3b, s3 = ops.attention_presplit(qi, kimg, vtimg, heads, split_out="also")
+    finally:
+        ops.attention_sched(prev)
+    assert torch.equal(a1, a3) and torch.equal(a3, a3b)
+    assert_split_equals(ops, s3, a3)
+    sh = lambda t: t.double().cpu().view(B, L, heads, 32).transpose(1, 2)
+    qd, kd, vd = (sh(qkv[..., i * C:(i + 1) * C].contiguous()) for i in range(3))
+    ref = F.scaled_dot_product_attention(qd, kd, vd).transpose(1, 2).reshape(B, L, C)
+    assert rel_err(a3, ref) < fused_tol()
