@@ -21,7 +21,7 @@ int igemm_launch_bx_pre2(int BM, int BN, int kgroups, bool uni, bool w8, dim3 gr
 int igemm_launch_bx_pre3(int BM, int BN, int kgroups, bool uni, bool w8, dim3 grid, hipStream_t st, const IgemmK& p);
 
 // DMA-fed kernel over pre-split operands (igemm_dma.hip)
-int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_dma(int BM, int BN, int nst, int parts, bool f16, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_config_ok(int BM, int BN, int nst, int parts);
 #ifdef ALDM_TEST_HOOKS
 extern std::atomic<int> g_debug_drop_product;   // test hook, igemm_dma.hip (libaldm_hip_testhooks.so only)
@@ -31,15 +31,15 @@ int igemm_launch_dma_ws(int BM, int BN, int nst, int parts, int blocks, hipStrea
 bool igemm_dma_ws_config_ok(int BM, int BN, int nst, int parts);
 int igemm_dma_ws_blocks_per_cu(int BM, int BN, int nst, int parts);
 // ... and its loader-wave form (igemm_dma_lw.hip): same grid, twice the waves per block
-int igemm_launch_dma_lw(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_dma_lw(int BM, int BN, int nst, int parts, bool f16, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_lw_config_ok(int BM, int BN, int nst, int parts);
 // ... and the operand-stationary form for short K (igemm_dma_os.hip): weight slab in registers, 32-row stages of the whole K
-int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_dma_os(int KT, int nst, int parts, bool f16, dim3 grid, hipStream_t st, const IgemmK& p);
 bool igemm_dma_os_config_ok(int KT, int nst, int parts);
 int igemm_dma_os_default_stages(int KT, int parts);
 // ... and the halo-patch form for 3x3 / stride-1 / pad-1 convolutions (igemm_dma_halo.hip): the A patch of a 32-channel block is
 // staged in LDS once for all nine taps
-int igemm_launch_dma_halo(int BM, int BN, int nstb, int wm, int parts, int maxch, dim3 grid, hipStream_t st, const IgemmK& p);
+int igemm_launch_dma_halo(int BM, int BN, int nstb, int wm, int parts, bool f16, int maxch, dim3 grid, hipStream_t st, const IgemmK& p);
 int igemm_dma_halo_maxch(int BM, int BN, int nstb, int wm, int parts, int nch);
 
 // split-K reduce: out = epi(sum_s ws[z][s][m][n]) — fixed summation order, one thread per element
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = r[j] > 0.0f ? r[j] : r[j] * d.out_split_slope;
         }
-        split_store4(d.out_split, orow, d.out_split_c, n, r, d.split_parts);
+        split_store4(d.out_split, orow, d.out_split_c, n, r, d.out_split_parts);
     }
 }
 
@@ -184,6 +184,32 @@ __global__ void pack_split_kernel(const float* __restrict__ src, uint4* __restri
             o.z = part[1][q][0];
             o.w = part[1][q][1];
             dst[((int64_t)ko * NP + q) * Npad + n] = o;
+        }
+    }
+}
+
+// packed fp32 [Kg][Npad][4] -> "f16x3" weight image [Ko][2][Npad][8 fp16]: hi / lo of scale * w (split4_f16)
+__global__ void pack_split_f16_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int Kg, int Npad, int Ko, float scale) {
+    const int64_t total = (int64_t)Ko * Npad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Npad);
+        const int ko = (int)(i / Npad);
+        u32x2 part[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kg = 2 * ko + h;
+            f32x4 f = {0.f, 0.f, 0.f, 0.f};
+            if (kg < Kg) f = *reinterpret_cast<const f32x4*>(src + ((int64_t)kg * Npad + n) * 4);
+            split4_f16(f, scale, part[h]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint4 o;
+            o.x = part[0][q][0];
+            o.y = part[0][q][1];
+            o.z = part[1][q][0];
+            o.w = part[1][q][1];
+            dst[((int64_t)ko * 2 + q) * Npad + n] = o;
         }
     }
 }
@@ -307,6 +333,11 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     if (!d.x1) d.x1 = reinterpret_cast<const float*>(d.a_split);  // never dereferenced on the DMA path
     if (d.split_parts == 0) d.split_parts = 3;
     ALDM_CHECK(d.split_parts == 2 || d.split_parts == 3, "aldm_igemm: split_parts must be 0 / 3 or 2");
+    if (d.out_split_parts == 0) d.out_split_parts = d.split_parts;
+    ALDM_CHECK(d.out_split_parts == 2 || d.out_split_parts == 3, "aldm_igemm: out_split_parts must be 0, 2 or 3");
+    ALDM_CHECK(d.a_fmt == ALDM_FMT_BF16 || (d.a_fmt == ALDM_FMT_F16 && d.a_split != nullptr && d.split_parts == 2 && d.acc_scale > 0.0f),
+               "aldm_igemm: a_fmt = ALDM_FMT_F16 needs a pre-split operand (a_split), 2-part images and acc_scale > 0");
+    if (d.a_fmt == ALDM_FMT_BF16) d.acc_scale = 1.0f;
     if (!d.x2) d.C2 = 0;
     if (d.pix1 == 0) d.pix1 = d.C1;
     if (d.pix2 == 0) d.pix2 = d.C2;
@@ -586,7 +617,8 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         if (ws_nst > 0) {
             // hinted / forced persistent form; a launch the persistent kernel cannot run (tuned tables are keyed by geometry,
             // not by epilogue flags) keeps the tile on igemm_dma_kernel with that tile's default ring
-            if (splits == 1 && igemm_dma_ws_config_ok(BM, BN, ws_nst, d.split_parts) && dma_ws_eligible(p, BM, BN)) {
+            if (splits == 1 && d.a_fmt == ALDM_FMT_BF16 && d.out_split_parts == d.split_parts &&
+                igemm_dma_ws_config_ok(BM, BN, ws_nst, d.split_parts) && dma_ws_eligible(p, BM, BN)) {
                 const int ntiles = p.tiles_m * p.tiles_n;
                 const int per = cdiv(ntiles, device_cus() * igemm_dma_ws_blocks_per_cu(BM, BN, ws_nst, d.split_parts));
                 p.ws = 1;
@@ -761,15 +793,15 @@ extern "C" int aldm_igemm(const aldm_igemm_desc* dd, void* stream) {
                    "(got dma=%d form=%d tile %dx%d, %d stages, %d parts) or clear the switch", p.dma, p.ws, BM, BN, p.nst, d.split_parts);
 #endif
     if (p.dma && p.ws == 4) {
-        rc = igemm_launch_dma_halo(BM, BN, p.nst, p.ws_blocks, d.split_parts, p.os_rows, grid, st, p);
+        rc = igemm_launch_dma_halo(BM, BN, p.nst, p.ws_blocks, d.split_parts, d.a_fmt == ALDM_FMT_F16, p.os_rows, grid, st, p);
     } else if (p.dma && p.ws == 3) {
-        rc = igemm_launch_dma_os(d.K / 32, p.nst, d.split_parts, grid, st, p);
+        rc = igemm_launch_dma_os(d.K / 32, p.nst, d.split_parts, d.a_fmt == ALDM_FMT_F16, grid, st, p);
     } else if (p.dma && p.ws == 2) {
-        rc = igemm_launch_dma_lw(BM, BN, p.nst, d.split_parts, grid, st, p);
+        rc = igemm_launch_dma_lw(BM, BN, p.nst, d.split_parts, d.a_fmt == ALDM_FMT_F16, grid, st, p);
     } else if (p.dma && p.ws) {
         rc = igemm_launch_dma_ws(BM, BN, p.nst, d.split_parts, p.ws_blocks, st, p);
     } else if (p.dma) {
-        rc = igemm_launch_dma(BM, BN, p.nst, d.split_parts, grid, st, p);
+        rc = igemm_launch_dma(BM, BN, p.nst, d.split_parts, d.a_fmt == ALDM_FMT_F16, grid, st, p);
     } else if (p.bx) {
         switch (pre) {
             case PRE_NONE: rc = igemm_launch_bx_pre0(BM, BN, p.kgroups, uni, w8, grid, st, p); break;
@@ -805,6 +837,20 @@ extern "C" int64_t aldm_split_bytes_parts(int K, int N, int parts) {
     return Ko * parts * Npad * 16;
 }
 extern "C" int64_t aldm_split_bytes(int K, int N) { return aldm_split_bytes_parts(K, N, 3); }
+
+extern "C" int aldm_pack_split_f16(const float* packed, void* dst, int K, int N, float scale, void* stream) {
+    ALDM_CHECK(packed && dst && K > 0 && N > 0 && scale > 0.0f, "aldm_pack_split_f16: bad args");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+               "aldm_pack_split_f16: operands must be 16-byte aligned");
+    const int Npad = (N + 31) / 32 * 32;
+    const int Kg = (K + 3) / 4;
+    const int Ko = 4 * ((K + 31) / 32);
+    const int64_t total = (int64_t)Ko * Npad;
+    hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, packed, reinterpret_cast<uint4*>(dst), Kg, Npad, Ko, scale);
+    ALDM_LAUNCH_CHECK("aldm_pack_split_f16");
+    return 0;
+}
 
 extern "C" int aldm_pack_split_bf16_parts(const float* packed, void* dst, int K, int N, int parts, void* stream) {
     ALDM_CHECK(packed && dst && K > 0 && N > 0 && (parts == 2 || parts == 3), "aldm_pack_split_bf16: bad args");

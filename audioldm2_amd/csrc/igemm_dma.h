@@ -46,6 +46,28 @@ constexpr int dma_blocks_per_cu(int BM, int BN, int NST, int NP) {
 // hipcc's own counter model sees it, so the fragment reads issued after the barrier are not waited for together with
 // the (already retired) older ones — an inline-asm wait is invisible to that model and cost an lgkmcnt(0) in front of
 // the second k-step's MFMAs.
+// the 32x32x16 matrix instruction of an operand format: bf16 parts, or the IEEE fp16 parts of the "f16x3" images (F16; the
+// registers hold either — the split images are typed by the launch, not by the kernel's operand arrays)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// F16 launches: the accumulators hold (s_a x) . (s_w w); acc_scale = 1 / (s_a s_w) (exact: powers of two) before the epilogue
+template <bool F16, int MT, int NT>
+__device__ __forceinline__ void unscale_acc(f32x16 (&acc)[MT][NT], float acc_scale) {
+    if constexpr (F16) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= acc_scale;
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
@@ -70,7 +92,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // DROP (test hook, aldm_debug_drop_product): leave out the first — smallest — partial product (hi_a x lo_w).  The result is a
 // deliberately broken "5-product" GEMM, ~1e-5 off: tests/test_dma_gpu.py asserts that it FAILS the fp32-grade bar, i.e. that the
 // bar would catch a kernel that silently lost a product.  Instantiated for ONE tile only (64x128, 2 stages, 3 parts).
-template <int BM, int BN, int NST, int WM = 2, int NP = 3, bool DROP = false>
+template <int BM, int BN, int NST, int WM = 2, int NP = 3, bool DROP = false, bool F16 = false>
 __global__ __launch_bounds__(128 * WM, dma_blocks_per_cu(BM, BN, NST, NP) * (WM / 2))
 void igemm_dma_kernel(const IgemmK p) {
     constexpr int WN = 2, NW = WM * WN;
@@ -82,6 +104,7 @@ void igemm_dma_kernel(const IgemmK p) {
     constexpr int D = NP * RA + NB;           // LDS-DMA instructions per thread and k-tile
     constexpr int NPROD = NP == 3 ? 6 : 3;    // bf16 partial products per fp32 product
     static_assert(NP == 2 || NP == 3, "2 or 3 parts");
+    static_assert(!F16 || NP == 2, "fp16 images have two parts");
     static_assert(BM % (16 * NW) == 0 && (4 * NP * (BN / 64)) % NW == 0, "DMA chunks must divide among the waves");
     static_assert(NST >= 2 && NST <= 8 && (NST - 1) * D <= 63, "ring depth / vmcnt range");
     static_assert(NW * 32 * (NT * 32 + 4) * 4 <= NST * STG * 16, "epilogue staging must fit the ring");
@@ -298,7 +321,7 @@ void igemm_dma_kernel(const IgemmK p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<F16>(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j]);
     };
     // wait until at most `n` k-tiles of this thread's DMA are still in flight (n is wave uniform)
     auto wait_tiles = [&](int n) {
@@ -378,6 +401,7 @@ void igemm_dma_kernel(const IgemmK p) {
     }
     return;
 #endif
+    unscale_acc<F16>(acc, d.acc_scale);
     igemm_epilogue<MT, NT>(p, acc, reinterpret_cast<float*>(&smem[0]), m0, n0, wave, wm, wn, lane, 0, split);
 }
 

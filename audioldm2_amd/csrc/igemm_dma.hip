@@ -21,7 +21,7 @@ bool igemm_dma_config_ok(int BM, int BN, int nst, int parts) {
 std::atomic<int> g_debug_drop_product{0};
 #endif
 
-int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+int igemm_launch_dma(int BM, int BN, int nst, int parts, bool f16, dim3 grid, hipStream_t st, const IgemmK& p) {
 #ifdef ALDM_TEST_HOOKS
     if (g_debug_drop_product.load(std::memory_order_relaxed)) {   // (aldm_igemm has checked the tile)
         if (!(BM == 64 && BN == 128 && nst == 2 && parts == 3)) return -1;
@@ -33,6 +33,30 @@ int igemm_launch_dma(int BM, int BN, int nst, int parts, dim3 grid, hipStream_t 
     hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 2, NP_>), grid, dim3(256), 0, st, p)
 #define ALDM_DMA8(BM_, BN_, NST_, NP_) \
     hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 4, NP_>), grid, dim3(512), 0, st, p)
+    if (f16) {   // "f16x3" images: the 2-part instantiations on the fp16 matrix instruction
+        if (parts != 2) return -1;
+#define ALDM_DMA_H(BM_, BN_, NST_) \
+    hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 2, 2, false, true>), grid, dim3(256), 0, st, p)
+#define ALDM_DMA8_H(BM_, BN_, NST_) \
+    hipLaunchKernelGGL((igemm_dma_kernel<BM_, BN_, NST_, 4, 2, false, true>), grid, dim3(512), 0, st, p)
+        if (BM == 256 && BN == 128 && nst == 3) ALDM_DMA8_H(256, 128, 3);
+        else if (BM == 256 && BN == 128 && nst == 2) ALDM_DMA8_H(256, 128, 2);
+        else if (BM == 128 && BN == 128 && nst == 4) ALDM_DMA_H(128, 128, 4);
+        else if (BM == 128 && BN == 128 && nst == 2) ALDM_DMA_H(128, 128, 2);
+        else if (BM == 64 && BN == 128 && nst == 6) ALDM_DMA_H(64, 128, 6);
+        else if (BM == 64 && BN == 128 && nst == 4) ALDM_DMA_H(64, 128, 4);
+        else if (BM == 64 && BN == 128 && nst == 2) ALDM_DMA_H(64, 128, 2);
+        else if (BM == 128 && BN == 64 && nst == 6) ALDM_DMA_H(128, 64, 6);
+        else if (BM == 128 && BN == 64 && nst == 4) ALDM_DMA_H(128, 64, 4);
+        else if (BM == 128 && BN == 64 && nst == 2) ALDM_DMA_H(128, 64, 2);
+        else if (BM == 64 && BN == 64 && nst == 6) ALDM_DMA_H(64, 64, 6);
+        else if (BM == 64 && BN == 64 && nst == 3) ALDM_DMA_H(64, 64, 3);
+        else if (BM == 64 && BN == 64 && nst == 2) ALDM_DMA_H(64, 64, 2);
+        else return -1;
+#undef ALDM_DMA_H
+#undef ALDM_DMA8_H
+        return 0;
+    }
     if (parts == 3) {
         if (BM == 256 && BN == 128 && nst == 2) ALDM_DMA8(256, 128, 2, 3);
         else if (BM == 128 && BN == 128 && nst == 3) ALDM_DMA(128, 128, 3, 3);
@@ -75,7 +99,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                                                          int C1, int C2, int64_t rows, int P,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, char* __restrict__ dst,
-                                                         char* __restrict__ dst_raw, int parts, float slope) {
+                                                         char* __restrict__ dst_raw, int parts, float slope, int raw_parts,
+                                                         float f16_scale) {
     const int C = C1 + C2;
     const int C8 = C >> 3;
     const int64_t total = rows * C8;
@@ -87,12 +112,13 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
         const int64_t off = (row * (C >> 5) + (c >> 5)) * (64 * parts) + (c & 31) * 2;
         u32x2 p0[3], p1[3];
-        if (dst_raw) {
-            split4_parts(v0, p0, parts);
-            split4_parts(v1, p1, parts);
+        if (dst_raw) {   // (always a bf16 image: the raw values have no a-priori bound)
+            const int64_t roff = (row * (C >> 5) + (c >> 5)) * (64 * raw_parts) + (c & 31) * 2;
+            split4_parts(v0, p0, raw_parts);
+            split4_parts(v1, p1, raw_parts);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                if (q < parts) *reinterpret_cast<u32x4*>(dst_raw + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+                if (q < raw_parts) *reinterpret_cast<u32x4*>(dst_raw + roff + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
         }
         if constexpr (AFF) {
             const int64_t so = (row / P) * C + c;
@@ -118,8 +144,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
                 v1[e] = v1[e] > 0.0f ? v1[e] : v1[e] * slope;
             }
         }
-        split4_parts(v0, p0, parts);
-        split4_parts(v1, p1, parts);
+        split4_fmt(v0, p0, parts, f16_scale);
+        split4_fmt(v1, p1, parts, f16_scale);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             if (q < parts) *reinterpret_cast<u32x4*>(dst + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
@@ -138,6 +164,9 @@ extern "C" int64_t aldm_split_image_bytes(int64_t rows, int C, int parts) { retu
 
 extern "C" int aldm_split_rows_act(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                                    const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, void* stream);
+extern "C" int aldm_split_rows_f16(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                                   const float* shift, int act, float slope, void* dst, void* dst_raw, int raw_parts, float f16_scale,
+                                   void* stream);
 
 extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                                const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream) {
@@ -145,8 +174,25 @@ extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2,
     return aldm_split_rows_act(x1, x2, C1, C2, rows, P, scale, shift, act, 0.f, dst, dst_raw, parts, stream);
 }
 
+static int split_rows_launch(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                             const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, int raw_parts,
+                             float f16_scale, void* stream);
+
 extern "C" int aldm_split_rows_act(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                                    const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, void* stream) {
+    return split_rows_launch(x1, x2, C1, C2, rows, P, scale, shift, act, slope, dst, dst_raw, parts, parts, 0.f, stream);
+}
+
+extern "C" int aldm_split_rows_f16(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                                   const float* shift, int act, float slope, void* dst, void* dst_raw, int raw_parts, float f16_scale,
+                                   void* stream) {
+    ALDM_CHECK(f16_scale > 0.0f && (raw_parts == 2 || raw_parts == 3), "aldm_split_rows_f16: need f16_scale > 0 and raw_parts 2 | 3");
+    return split_rows_launch(x1, x2, C1, C2, rows, P, scale, shift, act, slope, dst, dst_raw, 2, raw_parts, f16_scale, stream);
+}
+
+static int split_rows_launch(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                             const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, int raw_parts,
+                             float f16_scale, void* stream) {
     if (!x2) C2 = 0;
     const int C = C1 + C2;
     ALDM_CHECK(x1 && dst && rows > 0 && P > 0 && (parts == 2 || parts == 3), "aldm_split_rows: bad args");
@@ -164,7 +210,7 @@ extern "C" int aldm_split_rows_act(const float* x1, const float* x2, int C1, int
     hipStream_t st = (hipStream_t)stream;
 #define ALDM_SPLIT(A_, F_)                                                                                        \
     hipLaunchKernelGGL((split_rows_kernel<A_, F_>), dim3(blocks), dim3(256), 0, st, x1, x2, C1, C2, rows, P, scale, \
-                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw), parts, slope)
+                       shift, reinterpret_cast<char*>(dst), reinterpret_cast<char*>(dst_raw), parts, slope, raw_parts, f16_scale)
     if (scale) {
         if (act == ALDM_ACT_SILU) ALDM_SPLIT(ALDM_ACT_SILU, true);
         else if (act == ALDM_ACT_LRELU) ALDM_SPLIT(ALDM_ACT_LRELU, true);

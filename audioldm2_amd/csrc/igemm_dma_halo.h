@@ -46,7 +46,7 @@ constexpr int halo_lds_slots(int BN, int NSTB, int NP, int MAXCH) {
     return 2 * MAXCH * NP * 64 + NSTB * BN * 4 * NP + NP * 64;   // two patches, the weight ring, the zero region
 }
 
-template <int BM, int BN, int NSTB, int WM, int NP, int MAXCH>
+template <int BM, int BN, int NSTB, int WM, int NP, int MAXCH, bool F16 = false>
 __global__ __launch_bounds__(128 * WM, WM / 2)
 void igemm_dma_halo_kernel(const IgemmK p) {
     constexpr int WN = 2, NW = WM * WN;
@@ -259,7 +259,7 @@ void igemm_dma_halo_kernel(const IgemmK p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<F16>(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j]);
     };
     // wait until at most `n` k-tile groups of this wave's DMA are still in flight (n is wave uniform)
     auto wait_tiles = [&](int n) {
@@ -358,6 +358,7 @@ void igemm_dma_halo_kernel(const IgemmK p) {
     }
     return;
 #endif
+    unscale_acc<F16>(acc, d.acc_scale);
     igemm_epilogue<MT, NT>(p, acc, reinterpret_cast<float*>(&smem[0]), m0, n0, wave, wm, wn, lane, 0, split);
 }
 

@@ -34,7 +34,19 @@ int igemm_dma_halo_maxch(int BM, int BN, int nstb, int wm, int parts, int nch) {
     return best;
 }
 
-int igemm_launch_dma_halo(int BM, int BN, int nstb, int wm, int parts, int maxch, dim3 grid, hipStream_t st, const IgemmK& p) {
+int igemm_launch_dma_halo(int BM, int BN, int nstb, int wm, int parts, bool f16, int maxch, dim3 grid, hipStream_t st, const IgemmK& p) {
+    if (f16) {   // "f16x3" images: the 2-part instantiations on the fp16 matrix instruction
+#define X(BM_, BN_, NST_, WM_, NP_, CH_)                                                                                   \
+    if constexpr (NP_ == 2) {                                                                                              \
+        if (BM == BM_ && BN == BN_ && nstb == NST_ && wm == WM_ && parts == 2 && maxch == CH_) {                           \
+            hipLaunchKernelGGL((igemm_dma_halo_kernel<BM_, BN_, NST_, WM_, 2, CH_, true>), grid, dim3(128 * WM_), 0, st, p); \
+            return 0;                                                                                                      \
+        }                                                                                                                  \
+    }
+        ALDM_HALO_LIST(X)
+#undef X
+        return -1;
+    }
 #define X(BM_, BN_, NST_, WM_, NP_, CH_)                                                                             \
     if (BM == BM_ && BN == BN_ && nstb == NST_ && wm == WM_ && parts == NP_ && maxch == CH_) {                      \
         hipLaunchKernelGGL((igemm_dma_halo_kernel<BM_, BN_, NST_, WM_, NP_, CH_>), grid, dim3(128 * WM_), 0, st, p); \

@@ -12,7 +12,7 @@
 
 namespace aldm {
 
-template <int BM, int BN, int NST, int WM, int NP, int BPC>
+template <int BM, int BN, int NST, int WM, int NP, int BPC, bool F16 = false>
 __global__ __launch_bounds__(256 * WM, BPC * WM)
 void igemm_dma_lw_kernel(const IgemmK p) {
     constexpr int WN = 2, NW = WM * WN;
@@ -211,7 +211,7 @@ void igemm_dma_lw_kernel(const IgemmK p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<F16>(f.a[i][PA_[q]], f.b[j][PB_[q]], acc[i][j]);
     };
     constexpr int NMF = NPROD * MT * NT, NRD = NP * (MT + NT);
     __builtin_amdgcn_s_barrier();                           // P
@@ -245,6 +245,7 @@ void igemm_dma_lw_kernel(const IgemmK p) {
     mma_frags(f1);
     __builtin_amdgcn_s_waitcnt((7 << 4) | (3 << 14) | 15);   // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();   // every MMA wave is past its last fragment read: the ring becomes epilogue staging
+    unscale_acc<F16>(acc, d.acc_scale);
     igemm_epilogue<MT, NT>(p, acc, reinterpret_cast<float*>(&smem[0]), m0, n0, wave, wm, wn, lane, 0, split);
 }
 

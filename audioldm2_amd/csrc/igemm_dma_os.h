@@ -54,7 +54,9 @@ constexpr int os_lds_bytes(int KT, int NST, int NP) { return (NST * os_stage_slo
 // residual rows of stage t are fetched at the TOP of stage t — they land under the stage's MFMAs.
 enum { OS_EPI_PLAIN = 0, OS_EPI_GEGLU = 1, OS_EPI_QKV = 2 };
 
-template <int KT, int NST, int NP, int EPI>
+// NPO: parts of the split images the EPILOGUE writes (bf16 always); F16: the operands are "f16x3" images (NP = 2 fp16 parts of
+// power-of-two scaled values, acc_scale undoes the scaling in front of the epilogue) — such launches write 3-part images.
+template <int KT, int NST, int NP, int EPI, int NPO = NP, bool F16 = false>
 __global__ __launch_bounds__(512, 2)
 void igemm_dma_os_kernel(const IgemmK p) {
     constexpr int STG = os_stage_slots(KT, NP);
@@ -62,6 +64,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int ND = KT * NP / 4;            // LDS-DMA instructions per wave and stage (KT x 2 row groups x NP over 8 waves)
     static_assert(NP == 2 || NP == 3, "2 or 3 parts");
+    static_assert((NPO == 2 || NPO == 3) && (!F16 || NP == 2), "image formats");
     static_assert(KT % 4 == 0 && KT >= 4, "the k-tiles of a stage are split between four wave pairs");
     static_assert(NST >= 2 && NST <= 4 && (NST - 2) * ND <= 63, "ring depth / vmcnt range");
     static_assert(os_lds_bytes(KT, NST, NP) <= 160 * 1024, "ring + staging must fit the CU's LDS");
@@ -190,6 +193,12 @@ void igemm_dma_os_kernel(const IgemmK p) {
     };
 
     f32x4 acc[2];
+    auto mfma16 = [&](const bf16x8 a, const bf16x8 b, const f32x4 c) -> f32x4 {
+        if constexpr (F16)
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    };
     auto epilogue = [&](int t) {
         if ((ALDM_OS_ABLATE & 4) && p.M != -12345) {
             asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
@@ -235,7 +244,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
             const int m = m0 + g_er;
             if (m < p.M && g_cok) {
                 if (d.out) *reinterpret_cast<f32x4*>(d.out + (int64_t)m * d.ldo + g_ncol_o) = v;
-                if (d.out_split) split_store4_t<NP>(d.out_split, m, d.out_split_c, g_ncol_o, v);
+                if (d.out_split) split_store4_t<NPO>(d.out_split, m, d.out_split_c, g_ncol_o, v);
             }
             return;
         } else {
@@ -252,13 +261,13 @@ void igemm_dma_os_kernel(const IgemmK p) {
                     const int b = m0 / d.qkv_rows, tl = (m0 - b * d.qkv_rows) >> 5;
                     const int cc = n0 - 2 * d.qkv_c + wave * 16 + lc;
                     const int h = cc >> 5, dd = cc & 31;
-                    char* base = vt + ((((int64_t)b * heads + h) * tiles + tl) * NP) * 2048 + dd * 64 + (lg & 1) * 16 + (lg >> 1) * 8;
+                    char* base = vt + ((((int64_t)b * heads + h) * tiles + tl) * NPO) * 2048 + dd * 64 + (lg & 1) * 16 + (lg >> 1) * 8;
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         u32x2 part[3];
-                        split4_parts(acc[rt], part, NP);
+                        split4_parts(acc[rt], part, NPO);
 #pragma unroll
-                        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(base + q * 2048 + rt * 32) = part[q];
+                        for (int q = 0; q < NPO; ++q) *reinterpret_cast<u32x2*>(base + q * 2048 + rt * 32) = part[q];
                     }
                     return;
                 }
@@ -289,7 +298,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[rt][c] = v[rt][c] > 0.0f ? v[rt][c] : v[rt][c] * d.out_split_slope;
                         }
-                        split_store4_t<NP>(simg, m, simg_c, ncol - col_shift, v[rt]);
+                        split_store4_t<NPO>(simg, m, simg_c, ncol - col_shift, v[rt]);
                     }
                 }
             }
@@ -331,7 +340,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
             if (!(ALDM_OS_ABLATE & 2)) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt & 1][rt][PA_[0]], bw[kt][PB_[0]], acc[rt], 0, 0, 0);
+                    acc[rt] = mfma16(af[kt & 1][rt][PA_[0]], bw[kt][PB_[0]], acc[rt]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 1 < KT && !(ALDM_OS_ABLATE & 16)) {
@@ -348,7 +357,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
                 for (int q = 1; q < NPROD; ++q)
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt)
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt & 1][rt][PA_[q]], bw[kt][PB_[q]], acc[rt], 0, 0, 0);
+                        acc[rt] = mfma16(af[kt & 1][rt][PA_[q]], bw[kt][PB_[q]], acc[rt]);
             } else {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
@@ -356,6 +365,10 @@ void igemm_dma_os_kernel(const IgemmK p) {
                     for (int q = 0; q < NP; ++q) asm volatile("" ::"v"(af[kt & 1][rt][q]), "v"(bw[kt][q]));
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (F16) {   // (s_a x) . (s_w w) -> x . w: exact, powers of two
+            acc[0] *= d.acc_scale;
+            acc[1] *= d.acc_scale;
         }
         // Everything older than the newest NST - 2 stage issues has landed: stage t + 1 (issued one whole stage ago) and the
         // previous epilogue's stores.  Placed BEFORE an early wave's epilogue so that its loads / stores are not waited for.

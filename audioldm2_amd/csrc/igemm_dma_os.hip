@@ -17,9 +17,27 @@ int igemm_dma_os_default_stages(int KT, int parts) {
     return KT == 8 ? 4 : 3;
 }
 
-int igemm_launch_dma_os(int KT, int nst, int parts, dim3 grid, hipStream_t st, const IgemmK& p) {
+int igemm_launch_dma_os(int KT, int nst, int parts, bool f16, dim3 grid, hipStream_t st, const IgemmK& p) {
     // the epilogue form is a template parameter (igemm_dma_os.h, EPI): chosen here from the descriptor
     const int epi = p.d.epi_mode == ALDM_EPI_GEGLU ? OS_EPI_GEGLU : (p.d.epi_mode == ALDM_EPI_QKV ? OS_EPI_QKV : OS_EPI_PLAIN);
+    if (f16) {   // "f16x3" operands (2 fp16 parts); the epilogue writes 3-part bf16 images (K / V^T, the GEGLU output)
+        if (parts != 2 || p.d.out_split_parts != 3) return -1;
+#define ALDM_OS_H(KT_, NST_)                                                                                                   \
+    if (KT == KT_ && nst == NST_) {                                                                                            \
+        if (epi == OS_EPI_GEGLU) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_GEGLU, 3, true>), grid, dim3(512), 0, st, p); \
+        else if (epi == OS_EPI_QKV) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_QKV, 3, true>), grid, dim3(512), 0, st, p); \
+        else hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_PLAIN, 3, true>), grid, dim3(512), 0, st, p);        \
+        return 0;                                                                                                              \
+    }
+        ALDM_OS_H(8, 2)
+        ALDM_OS_H(8, 3)
+        ALDM_OS_H(8, 4)
+        ALDM_OS_H(12, 2)
+        ALDM_OS_H(12, 3)
+#undef ALDM_OS_H
+        return -1;
+    }
+    if (p.d.out_split_parts != parts) return -1;   // (bf16 launches write the image format they read)
 #define ALDM_OS_E(KT_, NST_, NP_, E_)                                                                            \
     hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_, E_>), grid, dim3(512), 0, st, p)
 #define ALDM_OS(KT_, NST_, NP_)                                                                                  \

@@ -86,6 +86,29 @@ __device__ __forceinline__ void split4_parts(const f32x4 v, u32x2 (&part)[3], in
     else split4(v, part);
 }
 
+// "f16x3" operands (aldm_igemm_desc.a_fmt = ALDM_FMT_F16): 2 parts, IEEE fp16, of the value scaled by an exact power of two:
+// hi = RN_f16(s x), lo = RN_f16(s x - hi) — 22 of the 24 significand bits while lo is a normal fp16, and an absolute error of at
+// most 2^-25 / s below that (the matrix core honours fp16 subnormals: profiles/r06_f16x3_accuracy.txt).  The producer's s puts
+// |s x| under 65504 by construction (a GroupNorm / LayerNorm output cannot exceed sqrt(n) max|gamma| + max|beta|); the clamp is a
+// seat belt that never engages inside that bound.
+using f16x4 = _Float16 __attribute__((ext_vector_type(4)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split4_f16(const f32x4 v, float s, u32x2 (&part)[3]) {
+    f32x4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = __builtin_fminf(__builtin_fmaxf(v[e] * s, -65504.0f), 65504.0f);
+    const f16x4 h = __builtin_convertvector(x, f16x4);
+    const f16x4 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), f16x4);
+    part[0] = __builtin_bit_cast(u32x2, h);
+    part[1] = __builtin_bit_cast(u32x2, l);
+    part[2] = u32x2{0u, 0u};
+}
+// the producers' store: f16_scale != 0 -> the 2-part fp16 image of f16_scale * v, else the `parts`-part bf16 image of v
+__device__ __forceinline__ void split4_fmt(const f32x4 v, u32x2 (&part)[3], int parts, float f16_scale) {
+    if (f16_scale != 0.f) split4_f16(v, f16_scale, part);
+    else split4_parts(v, part, parts);
+}
+
 // channels c .. c+3 (c % 4 == 0) of row `row` of a split image with Cs channels per row and `parts` parts
 __device__ __forceinline__ void split_store4(void* img, int64_t row, int Cs, int c, const f32x4 v, int parts = 3) {
     u32x2 part[3];
@@ -184,7 +207,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
             // 32-column tile j, half lh) holds rows (e & 3) + 8 (e >> 2) + 4 lh of a 32-row slab in registers e = 0..15:
             // registers 8s .. 8s + 7 are the 8 keys of chunk 2s + lh of its dim's 64-byte row.
             char* vt = reinterpret_cast<char*>(d.vt_split);
-            const int heads = d.qkv_c >> 5, parts = d.split_parts;
+            const int heads = d.qkv_c >> 5, parts = d.out_split_parts;
             const int tiles = d.qkv_rows >> 5;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -252,7 +275,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                     const int m = m0 + (wm * MT + i) * 32 + r;
                     if (m < p.M && cok && epi_st) {
                         if (go) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;
-                        if (simg) split_store4(simg, m, d.out_split_c, ncol_o, xv, d.split_parts);
+                        if (simg) split_store4(simg, m, d.out_split_c, ncol_o, xv, d.out_split_parts);
                     }
                 }
             }
@@ -362,7 +385,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                 }
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
-                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], simg_c, ncol - col_shift, v[it], d.split_parts);
+                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], simg_c, ncol - col_shift, v[it], d.out_split_parts);
             }
         } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
 #pragma unroll

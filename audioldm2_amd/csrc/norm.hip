@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ beta,
                                                          float* __restrict__ scale, float* __restrict__ shift, int gpb,
                                                          char* __restrict__ dst = nullptr, char* __restrict__ dst_raw = nullptr,
-                                                         int parts = 3, int act = ALDM_ACT_NONE) {
+                                                         int parts = 3, int act = ALDM_ACT_NONE, int raw_parts = 3,
+                                                         float f16_scale = 0.f) {
     const int C = C1 + C2;
     const int Cg4 = (C / G) >> 2;
     const int b = blockIdx.y;
@@ -203,13 +204,14 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                 f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
                 const int64_t off = (row * (C >> 5) + (c >> 5)) * (64 * parts) + (c & 31) * 2;
                 u32x2 p0[3], p1[3];
-                if (dst_raw) {
-                    split4_parts(v0, p0, parts);
-                    split4_parts(v1, p1, parts);
+                if (dst_raw) {   // (always a bf16 image: the raw values have no a-priori bound)
+                    const int64_t roff = (row * (C >> 5) + (c >> 5)) * (64 * raw_parts) + (c & 31) * 2;
+                    split4_parts(v0, p0, raw_parts);
+                    split4_parts(v1, p1, raw_parts);
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        if (q < parts)
-                            *reinterpret_cast<u32x4*>(dst_raw + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
+                        if (q < raw_parts)
+                            *reinterpret_cast<u32x4*>(dst_raw + roff + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                         v1[e] = silu_fast(v1[e]);
                     }
                 }
-                split4_parts(v0, p0, parts);
-                split4_parts(v1, p1, parts);
+                split4_fmt(v0, p0, parts, f16_scale);
+                split4_fmt(v1, p1, parts, f16_scale);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
                     if (q < parts) *reinterpret_cast<u32x4*>(dst + off + q * 64) = u32x4{p0[q][0], p0[q][1], p1[q][0], p1[q][1]};
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ y, int M, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        void* __restrict__ y_split, int parts) {
+                                                        void* __restrict__ y_split, int parts, float f16_scale) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
@@ -356,7 +358,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (c4 < C4) {
                 const f32x4 o = (v[r][i] - mean[r]) * rstd[r] * ga[i] + be[i];
                 if (yr) *reinterpret_cast<f32x4*>(yr + 4 * c4) = o;
-                if (y_split) split_store4(y_split, row0 + r, C, 4 * c4, o, parts);   // the next GEMM's pre-split A operand
+                if (y_split) {   // the next GEMM's pre-split A operand
+                    if (f16_scale != 0.f) {
+                        u32x2 part[3];
+                        split4_f16(o, f16_scale, part);
+                        char* base = reinterpret_cast<char*>(y_split) + ((int64_t)(row0 + r) * (C >> 5) + (c4 >> 3)) * 128 + (c4 & 7) * 8;
+                        *reinterpret_cast<u32x2*>(base) = part[0];
+                        *reinterpret_cast<u32x2*>(base + 64) = part[1];
+                    } else {
+                        split_store4(y_split, row0 + r, C, 4 * c4, o, parts);
+                    }
+                }
             }
         }
     }
@@ -440,10 +452,14 @@ extern "C" int64_t aldm_gn_ws_floats(int B, int P, int C, int G) {
 
 extern "C" int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                                const float* shift, int act, void* dst, void* dst_raw, int parts, void* stream);
+extern "C" int aldm_split_rows_f16(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                                   const float* shift, int act, float slope, void* dst, void* dst_raw, int raw_parts, float f16_scale,
+                                   void* stream);
 
 static int groupnorm_launch(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
                             const float* gamma, const float* beta, float* scale, float* shift, float* ws, void* dst,
-                            void* dst_raw, int parts, int act, void* stream) {
+                            void* dst_raw, int parts, int act, void* stream, int raw_parts = 0, float f16_scale = 0.f) {
+    if (raw_parts == 0) raw_parts = parts;
     if (!x2) C2 = 0;
     const int C = C1 + C2;
     ALDM_CHECK(x1 && scale && shift && ws, "aldm_groupnorm_stats: null pointer");
@@ -476,7 +492,7 @@ static int groupnorm_launch(const float* x1, const float* x2, int B, int P, int 
             // statistics + apply + activation + operand split in ONE launch (round 3)
             hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(gs, B), dim3(256), 0, st, x1, x2, P, C1, C2, G, fcols, frows, P, ws,
                                eps, gamma, beta, scale, shift, gpb, reinterpret_cast<char*>(dst),
-                               reinterpret_cast<char*>(dst_raw), parts, act);
+                               reinterpret_cast<char*>(dst_raw), parts, act, raw_parts, f16_scale);
             ALDM_LAUNCH_CHECK("aldm_groupnorm_split");
             return 0;
         }
@@ -489,8 +505,11 @@ static int groupnorm_launch(const float* x1, const float* x2, int B, int P, int 
                            beta, scale, shift);
     }
     ALDM_LAUNCH_CHECK("aldm_groupnorm_stats");
-    if (dst)   // the sample is too large for the one-launch form (or the slab does not split into 16-byte pieces)
+    if (dst) {   // the sample is too large for the one-launch form (or the slab does not split into 16-byte pieces)
+        if (f16_scale != 0.f)
+            return aldm_split_rows_f16(x1, x2, C1, C2, (int64_t)B * P, P, scale, shift, act, 0.f, dst, dst_raw, raw_parts, f16_scale, stream);
         return aldm_split_rows(x1, x2, C1, C2, (int64_t)B * P, P, scale, shift, act, dst, dst_raw, parts, stream);
+    }
     return 0;
 }
 
@@ -513,8 +532,21 @@ extern "C" int aldm_groupnorm_split(const float* x1, const float* x2, int B, int
     return groupnorm_launch(x1, x2, B, P, C1, C2, G, eps, gamma, beta, scale, shift, ws, dst, dst_raw, parts, act, stream);
 }
 
+// the "f16x3" forms (aldm_igemm_desc.a_fmt): the split image is the 2-part fp16 image of f16_scale * value
+extern "C" int aldm_groupnorm_split_f16(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
+                                        const float* gamma, const float* beta, int act, float* scale, float* shift, float* ws,
+                                        void* dst, void* dst_raw, int raw_parts, float f16_scale, void* stream) {
+    if (!x2) C2 = 0;
+    ALDM_CHECK(dst != nullptr && f16_scale > 0.0f && (raw_parts == 2 || raw_parts == 3) && (C1 + C2) % 32 == 0 && C1 % 8 == 0 && C2 % 8 == 0,
+               "aldm_groupnorm_split_f16: need dst, f16_scale > 0, raw_parts 2|3, (C1+C2) %% 32 == 0, C1 %% 8 == 0 (C1=%d C2=%d)", C1, C2);
+    ALDM_CHECK(act == ALDM_ACT_NONE || act == ALDM_ACT_SILU, "aldm_groupnorm_split_f16: activation %d not supported", act);
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dst_raw)) & 15) == 0,
+               "aldm_groupnorm_split_f16: split images must be 16-byte aligned");
+    return groupnorm_launch(x1, x2, B, P, C1, C2, G, eps, gamma, beta, scale, shift, ws, dst, dst_raw, 2, act, stream, raw_parts, f16_scale);
+}
+
 static int layernorm_launch(const float* x, float* y, void* y_split, int parts, int M, int C, const float* gamma,
-                            const float* beta, float eps, void* stream, const char* name, bool rms = false) {
+                            const float* beta, float eps, void* stream, const char* name, bool rms = false, float f16_scale = 0.f) {
     ALDM_CHECK(parts == 2 || parts == 3, "%s: parts must be 2 or 3", name);
     ALDM_CHECK(x && (y || y_split) && gamma && (beta || rms), "%s: null pointer", name);
     ALDM_CHECK(C % 4 == 0 && C <= 256 * LN_MAXV, "%s: C=%d must be a multiple of 4 and <= %d", name, C, 256 * LN_MAXV);
@@ -525,10 +557,10 @@ static int layernorm_launch(const float* x, float* y, void* y_split, int parts, 
     do {                                                                                                            \
         if (rms)                                                                                                    \
             hipLaunchKernelGGL((layernorm_kernel<V_, R_, true>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, C, \
-                               gamma, beta, eps, y_split, parts);                                                   \
+                               gamma, beta, eps, y_split, parts, f16_scale);                                        \
         else                                                                                                        \
             hipLaunchKernelGGL((layernorm_kernel<V_, R_, false>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, st, x, y, M, \
-                               C, gamma, beta, eps, y_split, parts);                                                \
+                               C, gamma, beta, eps, y_split, parts, f16_scale);                                     \
     } while (0)
     const int nv = cdiv(C / 4, 64);
     static const int env_r = [] {   // A/B override (tools/ln_bench.py): rows per wave for C <= 512
@@ -560,6 +592,12 @@ extern "C" int aldm_layernorm(const float* x, float* y, int M, int C, const floa
 extern "C" int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
                                     const float* beta, float eps, int parts, void* stream) {
     return layernorm_launch(x, y, y_split, parts, M, C, gamma, beta, eps, stream, "aldm_layernorm_split");
+}
+
+extern "C" int aldm_layernorm_split_f16(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
+                                        const float* beta, float eps, float f16_scale, void* stream) {
+    ALDM_CHECK(y_split != nullptr && f16_scale > 0.0f, "aldm_layernorm_split_f16: need y_split and f16_scale > 0");
+    return layernorm_launch(x, y, y_split, 2, M, C, gamma, beta, eps, stream, "aldm_layernorm_split_f16", false, f16_scale);
 }
 
 extern "C" int aldm_rmsnorm(const float* x, float* y, int M, int C, const float* weight, float eps, void* stream) {

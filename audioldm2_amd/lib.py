@@ -16,6 +16,7 @@ ABI_VERSION = 9
 ACT_NONE, ACT_SILU, ACT_LRELU, ACT_TANH, ACT_LOGCLAMP, ACT_GELU, ACT_GELU_TANH = range(7)
 B_PACKED, B_NT = 0, 1
 EPI_PLAIN, EPI_GEGLU, EPI_QKV = 0, 1, 2
+FMT_BF16, FMT_F16 = 0, 1
 
 
 class IgemmDesc(C.Structure):
@@ -48,6 +49,7 @@ class IgemmDesc(C.Structure):
         ("a_split", C.c_void_p), ("out_split", C.c_void_p), ("out_split_c", C.c_int32), ("split_parts", C.c_int32),
         ("out_split_act", C.c_int32), ("out_split_slope", C.c_float),
         ("k_split", C.c_void_p), ("vt_split", C.c_void_p), ("qkv_c", C.c_int32), ("qkv_rows", C.c_int32),
+        ("a_fmt", C.c_int32), ("acc_scale", C.c_float), ("out_split_parts", C.c_int32),
     ]
 
 
@@ -75,6 +77,14 @@ _SIGS = {
                                            C.c_void_p, C.c_float, C.c_void_p]),
     "aldm_split_bytes_parts": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "aldm_pack_split_bf16_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "aldm_pack_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "aldm_split_rows_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "aldm_groupnorm_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "aldm_layernorm_split_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_float, C.c_float, C.c_void_p]),
     "aldm_igemm_mma": (C.c_int, [C.c_int]),
     "aldm_split_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "aldm_pack_split_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

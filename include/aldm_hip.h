@@ -172,6 +172,18 @@ typedef struct aldm_igemm_desc {
     void* vt_split;
     int32_t qkv_c;         /* C = heads * 32                                                                         */
     int32_t qkv_rows;      /* rows (keys) per sample                                                                  */
+    /* ABI v9: "f16x3" operands.  a_fmt = ALDM_FMT_F16: a_split and w_split are 2-part images (split_parts = 2) whose parts are
+       IEEE fp16 — hi = RN_f16(s x), lo = RN_f16(s x - hi), s an exact power of two chosen by the producer so that |s x| <= 65504
+       holds by construction (GroupNorm / LayerNorm outputs: sqrt(n) max|gamma| + max|beta|; weights: their maximum) — and the fp32
+       product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 / 16x16x32_f16: three matrix instructions instead of bf16x6's
+       six, 22 of 24 significand bits per operand (measured 0.65 - 0.7x the fp32 MFMA's error against fp64:
+       profiles/r06_f16x3_accuracy.txt).  acc_scale = 1 / (s_a s_w) multiplies the accumulators before the epilogue (0 = 1).
+       out_split_parts: parts of the split images the EPILOGUE writes (out_split, k_split, vt_split), always bf16; 0 = split_parts.
+       DMA-fed launches only (aldm_split_rows_act / aldm_groupnorm_split / aldm_layernorm_split with f16_scale != 0 write such
+       images, aldm_pack_split_f16 the weights').                                                                      */
+    int32_t a_fmt;
+    float acc_scale;
+    int32_t out_split_parts;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -183,6 +195,7 @@ int64_t aldm_igemm_ws_floats(const aldm_igemm_desc* d);
 /* Host-only query (no launch): the block tile / split-K factor aldm_igemm would pick for this
  * descriptor and the algorithmic FLOPs of the call (2*M*N*K*batch) — used by bench.py's roofline
  * accounting.  splits / kgroups may be NULL.                                                              */
+enum { ALDM_FMT_BF16 = 0, ALDM_FMT_F16 = 1 };
 int aldm_igemm_plan(const aldm_igemm_desc* d, int* bm, int* bn, int64_t* flops, int* splits, int* kgroups,
                     int* mma);   /* mma: ALDM_MMA_* the launch would run on (may be NULL) */
 /* Host-only query: LDS ring depth of the DMA-fed kernel this descriptor launches (a_split set), 0 for the register-
@@ -226,6 +239,9 @@ int aldm_pack_split_bf16(const float* packed, void* dst, int K, int N, void* str
  * the "bf16x3" image of the DMA-fed kernel)                                                                     */
 int64_t aldm_split_bytes_parts(int K, int N, int parts);
 int aldm_pack_split_bf16_parts(const float* packed, void* dst, int K, int N, int parts, void* stream);
+/* the "f16x3" weight image (ABI v9): [k-octet][2 parts][Npad][8 fp16] of scale * w, scale an exact power of two with
+ * |scale * w| <= 65504 (the caller's: 2^floor(log2(32768 / max|w|))); same size as the 2-part bf16 image (aldm_split_bytes_parts(K, N, 2)) */
+int aldm_pack_split_f16(const float* packed, void* dst, int K, int N, float scale, void* stream);
 
 /* ---- split images: pre-split activations for the DMA-fed GEMM (aldm_igemm_desc.a_split, ABI v5) -----------------
  * A split image of channels-last fp32 rows [rows, C] (C % 32 == 0) holds every value as its exact 3-way truncation
@@ -245,6 +261,14 @@ int aldm_split_rows(const float* x1, const float* x2, int C1, int C2, int64_t ro
  * (hifigan/models.py:98, 151) applied once while writing the operand image                                          */
 int aldm_split_rows_act(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
                         const float* shift, int act, float slope, void* dst, void* dst_raw, int parts, void* stream);
+/* "f16x3" producers (ABI v9; aldm_igemm_desc.a_fmt): dst is the 2-part IEEE-fp16 image of f16_scale * value — hi = RN_f16, lo =
+ * RN_f16 of the remainder, 128 bytes per (row, 32-channel block) like a 2-part bf16 image — where f16_scale is an exact power of two
+ * under which the CALLER guarantees |f16_scale * value| <= 65504 (a GroupNorm output cannot exceed sqrt(elements per group) *
+ * max|gamma| + max|beta|, a LayerNorm output sqrt(C) * max|gamma| + max|beta|, SiLU only shrinks; values beyond are clamped).
+ * dst_raw stays a bf16 image with raw_parts parts: raw activations have no a-priori bound.                                  */
+int aldm_split_rows_f16(const float* x1, const float* x2, int C1, int C2, int64_t rows, int P, const float* scale,
+                        const float* shift, int act, float slope, void* dst, void* dst_raw, int raw_parts, float f16_scale,
+                        void* stream);
 
 /* Pack a weight for ALDM_B_PACKED.  src is the PyTorch layout:
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1
@@ -277,12 +301,17 @@ int64_t aldm_gn_ws_floats(int B, int P, int C, int G);
 int aldm_groupnorm_split(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
                          const float* gamma, const float* beta, int act, float* scale, float* shift, float* ws,
                          void* dst, void* dst_raw, int parts, void* stream);
+int aldm_groupnorm_split_f16(const float* x1, const float* x2, int B, int P, int C1, int C2, int G, float eps,
+                             const float* gamma, const float* beta, int act, float* scale, float* shift, float* ws,
+                             void* dst, void* dst_raw, int raw_parts, float f16_scale, void* stream);
 /* LayerNorm over the last dim of [M, C] (attention.py:393-395), eps 1e-5                   */
 int aldm_layernorm(const float* x, float* y, int M, int C, const float* gamma,
                    const float* beta, float eps, void* stream);
 /* same, writing the result as a split image (y_split, C % 32 == 0) and optionally also as fp32 (y may be NULL)    */
 int aldm_layernorm_split(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
                          const float* beta, float eps, int parts, void* stream);
+int aldm_layernorm_split_f16(const float* x, float* y, void* y_split, int M, int C, const float* gamma,
+                             const float* beta, float eps, float f16_scale, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------ */
 /* Multi-head attention, head dim 32, flash-style online softmax on fp32 MFMA:
