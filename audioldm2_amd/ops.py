@@ -45,28 +45,74 @@ def _chk(t: torch.Tensor, name: str):
 #             fp64 (plain bf16: 2.9e-3; tools/x3_accuracy.py); the 200-step waveform matches the reference to 1.4e-6 rms, 700x
 #             inside north_star's 1e-3 — but its operands ARE narrower than fp32, so it is reported as a named sub-record
 #             (`fast`), never as the headline.  Launches without a pre-split operand run "bf16x6" in this mode too.
+#   "f16x3"   round 6, opt-in, reported as a named sub-record: the GEMMs whose A operand comes out of a GroupNorm or a LayerNorm — the
+#             ResBlocks' 3x3 convs, proj_in, q / k / v, the GEGLU projection; the VAE's ResnetBlock convs: ~2/3 of the UNet's FLOPs —
+#             take 2-part IEEE-fp16 images of power-of-two scaled operands (a normalised tensor has an a-priori bound, sqrt(n) max|gamma|
+#             + max|beta|, so the scale is known before the data; weights are scaled by their maximum) and evaluate hi*hi + hi*lo +
+#             lo*hi on the fp16 matrix instruction: THREE MFMAs per fp32 product with 22 of 24 significand bits per operand — measured
+#             0.65-0.7x the fp32 MFMA's own error against fp64 (profiles/r06_f16x3_accuracy.txt).  Every other launch (operands
+#             without a bound: GEMM / attention outputs, raw activations) runs "bf16x6", attention included.
 MMA_MODE = os.environ.get("ALDM_MMA", "bf16x6")
-assert MMA_MODE in ("f32", "bf16x6", "bf16x3"), MMA_MODE
+MMA_MODES = ("f32", "bf16x6", "bf16x3", "f16x3")
+assert MMA_MODE in MMA_MODES, MMA_MODE
 
 
 def set_mma(mode: str) -> str:
-    """Select the matrix-core path for subsequent igemm launches ("f32" | "bf16x6" | "bf16x3"); returns the previous
+    """Select the matrix-core path for subsequent igemm launches ("f32" | "bf16x6" | "bf16x3" | "f16x3"); returns the previous
     one.  Captured HIP graphs keep the path they were captured with."""
     global MMA_MODE
-    assert mode in ("f32", "bf16x6", "bf16x3"), mode
+    assert mode in MMA_MODES, mode
     prev, MMA_MODE = MMA_MODE, mode
     if _l._lib is not None or os.path.exists(_l.LIB_PATH):
         try:  # the attention kernel follows the engine's mode unless $ALDM_ATTN_MMA pins it
             if "ALDM_ATTN_MMA" not in os.environ:
-                _l.load().aldm_attention_mma({"f32": 1, "bf16x6": 2, "bf16x3": 3}[mode])
+                _l.load().aldm_attention_mma({"f32": 1, "bf16x6": 2, "bf16x3": 3, "f16x3": 2}[mode])
         except RuntimeError:
             pass
     return prev
 
 
 def split_parts() -> int:
-    """Parts per operand of the split images the current mode produces / consumes."""
+    """Parts per operand of the bf16 split images the current mode produces / consumes ("f16x3": the images GEMM and attention
+    epilogues write are 3-part bf16; only the GroupNorm / LayerNorm producers write fp16 images there)."""
     return 2 if MMA_MODE == "bf16x3" else 3
+
+
+def f16_mode() -> bool:
+    return MMA_MODE == "f16x3"
+
+
+def _pow2_scale(bound: float) -> float:
+    """The largest power of two s with s * bound <= 32768 (a factor two under fp16's 65504: the bound is mathematical, the slack
+    covers fp32 rounding of the normalisation itself)."""
+    import math
+    if not (bound > 0.0) or not math.isfinite(bound):
+        return 1.0
+    return float(2.0 ** math.floor(math.log2(32768.0 / bound)))
+
+
+def _absmax_cached(t: Optional[torch.Tensor]) -> float:
+    """max|t| of a parameter tensor, read once (one host sync, before any graph capture: every model runs an eager step first) and
+    kept ON the tensor object together with its version counter (not keyed by data_ptr: the allocator reuses addresses)."""
+    if t is None:
+        return 0.0
+    c = getattr(t, "_aldm_absmax", None)
+    if c is None or c[0] != t._version:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("f16x3: the bound of a normalisation's parameters must be known before graph capture (run one eager step)")
+        c = (t._version, float(t.detach().abs().max()))
+        try:
+            t._aldm_absmax = c
+        except (AttributeError, RuntimeError):
+            pass
+    return c[1]
+
+
+def _norm_f16_scale(gamma: torch.Tensor, beta: Optional[torch.Tensor], n: int) -> float:
+    """fp16 image scale of a GroupNorm / LayerNorm output normalised over n elements: |gamma x_hat + beta| <= sqrt(n) max|gamma| +
+    max|beta| (|x_hat| <= sqrt(n) holds for any data; SiLU only shrinks)."""
+    import math
+    return _pow2_scale(math.sqrt(float(n)) * _absmax_cached(gamma) + _absmax_cached(beta))
 
 
 @dataclass
@@ -81,10 +127,25 @@ class Packed:
     bias: Optional[torch.Tensor] = None
     split: Optional[torch.Tensor] = None
     split2: Optional[torch.Tensor] = None   # the 2-part ("bf16x3") image, DMA-fed launches only
+    split16: Optional[torch.Tensor] = None  # the 2-part fp16 ("f16x3") image of w_scale * w
+    w_scale: float = 0.0                    # ... its power-of-two scale
 
     @property
     def K(self) -> int:
         return self.KH * self.KW * self.Cin
+
+    def split16_ptr(self) -> int:
+        """Device pointer of the "f16x3" weight image (built on first use, before any graph capture): hi / lo fp16 of w_scale * w,
+        w_scale = the largest power of two that keeps max|w| under 32768."""
+        if self.split16 is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("a weight's fp16 split image must exist before graph capture (run one eager step)")
+            lib = _l.load()
+            self.w_scale = _pow2_scale(float(self.data.abs().max()))
+            self.split16 = torch.empty(lib.aldm_split_bytes_parts(self.K, self.N, 2) // 4, device=self.data.device, dtype=torch.int32)
+            _l.check(lib.aldm_pack_split_f16(self.data.data_ptr(), self.split16.data_ptr(), self.K, self.N, self.w_scale, _stream()),
+                     "pack_split_f16")
+        return self.split16.data_ptr()
 
     def split_ptr(self, parts: int = 3) -> Optional[int]:
         """Device pointer of the bf16-split image with `parts` parts (built on first use) or None in fp32 mode."""
@@ -114,23 +175,27 @@ class Packed:
 class SplitT:
     """A split image (include/aldm_hip.h "split images"): the exact 3-way bf16 split of a channels-last fp32 tensor of
     logical shape `shape` = [..., C], stored [rows, C/32, 3, 32] as int16 — the pre-split A operand of the DMA-fed GEMM."""
-    __slots__ = ("data", "shape")
+    __slots__ = ("data", "shape", "fmt", "scale")
 
-    def __init__(self, data: torch.Tensor, shape):
+    def __init__(self, data: torch.Tensor, shape, fmt: str = "bf16", scale: float = 1.0):
         self.data = data
         self.shape = tuple(shape)
+        self.fmt = fmt        # "bf16" | "f16" (the "f16x3" image: 2 parts, IEEE fp16, of scale * value)
+        self.scale = scale
 
     @property
     def parts(self) -> int:
         return self.data.shape[2]
 
     @staticmethod
-    def empty(shape, device, parts: Optional[int] = None) -> "SplitT":
+    def empty(shape, device, parts: Optional[int] = None, f16_scale: float = 0.0) -> "SplitT":
         C_ = shape[-1]
         assert C_ % 32 == 0, f"split image needs C % 32 == 0, got {C_}"
         rows = 1
         for s_ in shape[:-1]:
             rows *= s_
+        if f16_scale:
+            return SplitT(torch.empty((rows, C_ // 32, 2, 32), device=device, dtype=torch.int16), shape, "f16", f16_scale)
         return SplitT(torch.empty((rows, C_ // 32, parts or split_parts(), 32), device=device, dtype=torch.int16), shape)
 
     @property
@@ -156,10 +221,13 @@ class SplitT:
         tot = self.rows * self.C
         shape = tuple(tot // n if s_ == -1 else s_ for s_ in shape)
         assert shape[-1] == self.C, "a split image can only be re-viewed over its row dimensions"
-        return SplitT(self.data, shape)
+        return SplitT(self.data, shape, self.fmt, self.scale)
 
     def float(self) -> torch.Tensor:
-        """hi + mid + lo back to fp32 (tests / debugging): exact."""
+        """hi + mid + lo back to fp32 (tests / debugging): exact for bf16 images; (hi + lo) / scale for an fp16 image."""
+        if self.fmt == "f16":
+            h = self.data.view(torch.float16).float()
+            return ((h[:, :, 0] + h[:, :, 1]) / self.scale).reshape(self.shape)
         parts = (self.data.to(torch.int32) << 16).view(torch.float32)
         acc = parts[:, :, 0] + parts[:, :, 1]
         if self.parts == 3:
@@ -179,7 +247,7 @@ def set_dma(on: bool) -> bool:
 
 
 def use_dma() -> bool:
-    return DMA_MODE and MMA_MODE in ("bf16x6", "bf16x3")
+    return DMA_MODE and MMA_MODE in ("bf16x6", "bf16x3", "f16x3")
 
 
 def split_rows(x: torch.Tensor, x2: Optional[torch.Tensor] = None, pre=None, act: int = ACT_NONE,
@@ -275,6 +343,21 @@ def _tuned_table(bx=False):
                     with open(path) as f:
                         _TUNED[mode] = {k: v[:5] if mode is True else v[:4] for k, v in json.load(f)["entries"].items()}
     return _TUNED[bx]
+
+
+def _set_split_operand(d: IgemmDesc, x: "SplitT", pw: "Packed", so: Optional["SplitT"] = None) -> None:
+    """a_split / w_split / image formats of a DMA-fed launch over the split image x (and its split-image output so)."""
+    d.a_split = x.data_ptr()
+    d.split_parts = x.parts
+    if x.fmt == "f16":
+        d.a_fmt = _l.FMT_F16
+        d.w_split = pw.split16_ptr()
+        d.acc_scale = 1.0 / (x.scale * pw.w_scale)
+        d.out_split_parts = so.parts if so is not None else 3
+    else:
+        d.w_split = pw.split_ptr(x.parts)
+        if so is not None:
+            assert so.parts == x.parts and so.fmt == "bf16"
 
 
 def _igemm(d: IgemmDesc, what: str, device=None):
@@ -455,17 +538,16 @@ def linear_geglu(x, pw: Packed, split_out: Optional[str] = None, gate_act: int =
     so = SplitT.empty(oshape, x.device) if split_out else None
     d = IgemmDesc()
     if is_split:
-        d.a_split = x.data_ptr(); d.split_parts = x.parts
+        _set_split_operand(d, x, pw, so)
     else:
         d.x1 = x.data_ptr(); d.split_parts = 3
-    assert so is None or so.parts == d.split_parts or not is_split
+        d.w_split = pw.split_ptr(3)
     if so is not None and not is_split:
         d.split_parts = so.parts
     d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
-    d.w_split = pw.split_ptr(x.parts if is_split else 3)
     d.bias = _p(pw.bias); d.out = _p(out); d.ldo = pw.N // 2; d.alpha = 1.0
     if so is not None:
         d.out_split = so.data_ptr(); d.out_split_c = pw.N // 2
@@ -486,18 +568,18 @@ def linear_qkv(x: "SplitT", pw: Packed, heads: int, rows_per_sample: int):
     M = x.rows
     assert M % rows_per_sample == 0 and rows_per_sample % 32 == 0
     Bn = M // rows_per_sample
-    P = x.parts
+    P = 3 if x.fmt == "f16" else x.parts   # the K / V^T images are bf16 (the attention runs bf16x6 behind f16x3 projections)
     dev = x.device
     q = torch.empty((*x.shape[:-1], Cq), device=dev, dtype=torch.float32)
     k_img = torch.empty((M, heads, P, 32), device=dev, dtype=torch.int16)
     vt_img = torch.empty((Bn, heads, rows_per_sample // 32, P, 32, 32), device=dev, dtype=torch.int16)
     d = IgemmDesc()
-    d.a_split = x.data_ptr(); d.split_parts = P
+    _set_split_operand(d, x, pw)
+    d.out_split_parts = P
     d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.K = pw.K; d.N = pw.N
-    d.w_split = pw.split_ptr(P)
     d.out = q.data_ptr(); d.ldo = Cq; d.alpha = 1.0
     d.k_split = k_img.data_ptr(); d.vt_split = vt_img.data_ptr(); d.qkv_c = Cq; d.qkv_rows = rows_per_sample
     d.epi_mode = _l.EPI_QKV; d.batch = 1
@@ -600,7 +682,7 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
         bias = pw.bias
     d = IgemmDesc()
     if is_split:
-        d.a_split = x.data_ptr(); d.split_parts = x.parts
+        _set_split_operand(d, x, pw, so)
     else:
         d.x1 = x.data_ptr(); d.split_parts = so.parts if so is not None else 3
     d.x2 = _p(x2)
@@ -615,7 +697,8 @@ def conv(x: torch.Tensor, pw: Packed, *, stride=(1, 1), pad=(0, 0), dil=(1, 1), 
     d.w = pw.data.data_ptr(); d.b_mode = B_PACKED; d.ldb = 0
     # register-staged launches always use the 3-part weight image; a 2-part out_split from them needs split_parts = 2,
     # which rules the bf16-split register-staged kernel out (fp32 MFMA then): only DMA-fed launches write 2-part images
-    d.w_split = pw.split_ptr(x.parts if is_split else 3)
+    if not is_split:
+        d.w_split = pw.split_ptr(3)
     d.K = pw.K; d.N = N
     d.bias = _p(bias); d.rowbias = _p(rowbias); d.res = _p(res); d.out = _p(out)
     if so is not None:
@@ -751,8 +834,15 @@ def gn_split(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups
     ws = torch.empty(lib.aldm_gn_ws_floats(B, P, Cc, groups), device=x.device, dtype=torch.float32)
     ss = torch.empty((2, B, Cc), device=x.device, dtype=torch.float32)
     shape = (*x.shape[:-1], Cc)
-    dst = SplitT.empty(shape, x.device)
     raw = SplitT.empty(shape, x.device) if want_raw else None
+    if f16_mode():
+        # "f16x3": the normalised (and SiLU'd) tensor as a 2-part fp16 image; its bound is known before the data
+        dst = SplitT.empty(shape, x.device, f16_scale=_norm_f16_scale(gamma, beta, (Cc // groups) * P))
+        _l.check(lib.aldm_groupnorm_split_f16(x.data_ptr(), _p(x2), B, P, C1, C2, groups, eps, gamma.data_ptr(), beta.data_ptr(), act,
+                                              ss[0].data_ptr(), ss[1].data_ptr(), ws.data_ptr(), dst.data_ptr(),
+                                              None if raw is None else raw.data_ptr(), 3, dst.scale, _stream()), "groupnorm_split_f16")
+        return (dst, raw) if want_raw else dst
+    dst = SplitT.empty(shape, x.device)
     _l.check(lib.aldm_groupnorm_split(x.data_ptr(), _p(x2), B, P, C1, C2, groups, eps, gamma.data_ptr(), beta.data_ptr(), act,
                                       ss[0].data_ptr(), ss[1].data_ptr(), ws.data_ptr(), dst.data_ptr(),
                                       None if raw is None else raw.data_ptr(), dst.parts, _stream()), "groupnorm_split")
@@ -771,6 +861,11 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         _l.check(_l.load().aldm_layernorm(x.data_ptr(), y.data_ptr(), M, Cc, gamma.data_ptr(),
                                           beta.data_ptr(), eps, _stream()), "layernorm")
         return y
+    if f16_mode():
+        so = SplitT.empty(x.shape, x.device, f16_scale=_norm_f16_scale(gamma, beta, Cc))
+        _l.check(_l.load().aldm_layernorm_split_f16(x.data_ptr(), _p(y), so.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), eps,
+                                                    so.scale, _stream()), "layernorm_split_f16")
+        return so if split_out == "only" else (y, so)
     so = SplitT.empty(x.shape, x.device)
     _l.check(_l.load().aldm_layernorm_split(x.data_ptr(), _p(y), so.data_ptr(), M, Cc, gamma.data_ptr(),
                                             beta.data_ptr(), eps, so.parts, _stream()), "layernorm_split")

@@ -39,7 +39,7 @@ def gold(name):
 # The product modes the parity tests pin END TO END: "bf16x6" — the library default, fp32-grade, the mode
 # bench.py's headline is measured in — and "bf16x3", the opt-in fast mode behind bench.py's `fast` sub-record.  Tests without the
 # parameter run the default.
-MODES = ["bf16x6", "bf16x3"]
+MODES = ["bf16x6", "bf16x3", "f16x3"]   # f16x3 (round 6): held to the fp32-grade bars, like bf16x6
 
 
 @pytest.fixture(params=MODES)
