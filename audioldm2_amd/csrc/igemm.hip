@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmK p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = r[j] > 0.0f ? r[j] : r[j] * d.out_split_slope;
         }
-        split_store4(d.out_split, orow, d.out_split_c, n, r, d.out_split_parts);
+        split_store4_out(d, d.out_split, orow, d.out_split_c, n, r);
     }
 }
 
@@ -338,6 +338,10 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.a_fmt == ALDM_FMT_BF16 || (d.a_fmt == ALDM_FMT_F16 && d.a_split != nullptr && d.split_parts == 2 && d.acc_scale > 0.0f),
                "aldm_igemm: a_fmt = ALDM_FMT_F16 needs a pre-split operand (a_split), 2-part images and acc_scale > 0");
     if (d.a_fmt == ALDM_FMT_BF16) d.acc_scale = 1.0f;
+    ALDM_CHECK(d.out_split_fmt == ALDM_FMT_BF16 || (d.out_split_fmt == ALDM_FMT_F16 && d.out_split != nullptr && d.out_split_scale > 0.0f &&
+                                                   d.epi_mode != ALDM_EPI_QKV),
+               "aldm_igemm: out_split_fmt = ALDM_FMT_F16 needs out_split, out_split_scale > 0 and a plain or GEGLU epilogue");
+    if (d.out_split_fmt == ALDM_FMT_F16) d.out_split_parts = 2;
     if (!d.x2) d.C2 = 0;
     if (d.pix1 == 0) d.pix1 = d.C1;
     if (d.pix2 == 0) d.pix2 = d.C2;
@@ -617,7 +621,7 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
         if (ws_nst > 0) {
             // hinted / forced persistent form; a launch the persistent kernel cannot run (tuned tables are keyed by geometry,
             // not by epilogue flags) keeps the tile on igemm_dma_kernel with that tile's default ring
-            if (splits == 1 && d.a_fmt == ALDM_FMT_BF16 && d.out_split_parts == d.split_parts &&
+            if (splits == 1 && d.a_fmt == ALDM_FMT_BF16 && d.out_split_parts == d.split_parts && d.out_split_fmt == ALDM_FMT_BF16 &&
                 igemm_dma_ws_config_ok(BM, BN, ws_nst, d.split_parts) && dma_ws_eligible(p, BM, BN)) {
                 const int ntiles = p.tiles_m * p.tiles_n;
                 const int per = cdiv(ntiles, device_cus() * igemm_dma_ws_blocks_per_cu(BM, BN, ws_nst, d.split_parts));

@@ -56,7 +56,8 @@ enum { OS_EPI_PLAIN = 0, OS_EPI_GEGLU = 1, OS_EPI_QKV = 2 };
 
 // NPO: parts of the split images the EPILOGUE writes (bf16 always); F16: the operands are "f16x3" images (NP = 2 fp16 parts of
 // power-of-two scaled values, acc_scale undoes the scaling in front of the epilogue) — such launches write 3-part images.
-template <int KT, int NST, int NP, int EPI, int NPO = NP, bool F16 = false>
+// FO: out_split is the 2-part fp16 image of out_split_scale * result (the GEGLU output feeding an f16x3 FF-out GEMM).
+template <int KT, int NST, int NP, int EPI, int NPO = NP, bool F16 = false, bool FO = false>
 __global__ __launch_bounds__(512, 2)
 void igemm_dma_os_kernel(const IgemmK p) {
     constexpr int STG = os_stage_slots(KT, NP);
@@ -244,7 +245,10 @@ void igemm_dma_os_kernel(const IgemmK p) {
             const int m = m0 + g_er;
             if (m < p.M && g_cok) {
                 if (d.out) *reinterpret_cast<f32x4*>(d.out + (int64_t)m * d.ldo + g_ncol_o) = v;
-                if (d.out_split) split_store4_t<NPO>(d.out_split, m, d.out_split_c, g_ncol_o, v);
+                if (d.out_split) {
+                    if constexpr (FO) split_store4_f16(d.out_split, m, d.out_split_c, g_ncol_o, v, d.out_split_scale);
+                    else split_store4_t<NPO>(d.out_split, m, d.out_split_c, g_ncol_o, v);
+                }
             }
             return;
         } else {
@@ -298,7 +302,8 @@ void igemm_dma_os_kernel(const IgemmK p) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[rt][c] = v[rt][c] > 0.0f ? v[rt][c] : v[rt][c] * d.out_split_slope;
                         }
-                        split_store4_t<NPO>(simg, m, simg_c, ncol - col_shift, v[rt]);
+                        if constexpr (FO && EPI == OS_EPI_PLAIN) split_store4_f16(simg, m, simg_c, ncol - col_shift, v[rt], d.out_split_scale);
+                        else split_store4_t<NPO>(simg, m, simg_c, ncol - col_shift, v[rt]);
                     }
                 }
             }

@@ -21,10 +21,13 @@ int igemm_launch_dma_os(int KT, int nst, int parts, bool f16, dim3 grid, hipStre
     // the epilogue form is a template parameter (igemm_dma_os.h, EPI): chosen here from the descriptor
     const int epi = p.d.epi_mode == ALDM_EPI_GEGLU ? OS_EPI_GEGLU : (p.d.epi_mode == ALDM_EPI_QKV ? OS_EPI_QKV : OS_EPI_PLAIN);
     if (f16) {   // "f16x3" operands (2 fp16 parts); the epilogue writes 3-part bf16 images (K / V^T, the GEGLU output)
-        if (parts != 2 || p.d.out_split_parts != 3) return -1;
+        const bool fo = p.d.out_split_fmt == ALDM_FMT_F16;
+        if (parts != 2 || (!fo && p.d.out_split_parts != 3) || (fo && epi == OS_EPI_QKV)) return -1;
 #define ALDM_OS_H(KT_, NST_)                                                                                                   \
     if (KT == KT_ && nst == NST_) {                                                                                            \
-        if (epi == OS_EPI_GEGLU) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_GEGLU, 3, true>), grid, dim3(512), 0, st, p); \
+        if (fo && epi == OS_EPI_GEGLU) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_GEGLU, 3, true, true>), grid, dim3(512), 0, st, p); \
+        else if (fo) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_PLAIN, 3, true, true>), grid, dim3(512), 0, st, p); \
+        else if (epi == OS_EPI_GEGLU) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_GEGLU, 3, true>), grid, dim3(512), 0, st, p); \
         else if (epi == OS_EPI_QKV) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_QKV, 3, true>), grid, dim3(512), 0, st, p); \
         else hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_PLAIN, 3, true>), grid, dim3(512), 0, st, p);        \
         return 0;                                                                                                              \
@@ -37,7 +40,7 @@ int igemm_launch_dma_os(int KT, int nst, int parts, bool f16, dim3 grid, hipStre
 #undef ALDM_OS_H
         return -1;
     }
-    if (p.d.out_split_parts != parts) return -1;   // (bf16 launches write the image format they read)
+    if (p.d.out_split_parts != parts || p.d.out_split_fmt != ALDM_FMT_BF16) return -1;   // (bf16 launches write the image format they read)
 #define ALDM_OS_E(KT_, NST_, NP_, E_)                                                                            \
     hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, NP_, E_>), grid, dim3(512), 0, st, p)
 #define ALDM_OS(KT_, NST_, NP_)                                                                                  \

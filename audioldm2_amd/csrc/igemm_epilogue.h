@@ -119,6 +119,20 @@ __device__ __forceinline__ void split_store4(void* img, int64_t row, int Cs, int
         if (q < parts) *reinterpret_cast<u32x2*>(base + q * 64) = part[q];
 }
 
+// channels c .. c+3 of row `row` of a 2-part fp16 ("f16x3") image of scale * v
+__device__ __forceinline__ void split_store4_f16(void* img, int64_t row, int Cs, int c, const f32x4 v, float scale) {
+    u32x2 part[3];
+    split4_f16(v, scale, part);
+    char* base = reinterpret_cast<char*>(img) + (row * (Cs >> 5) + (c >> 5)) * 128 + (c & 31) * 2;
+    *reinterpret_cast<u32x2*>(base) = part[0];
+    *reinterpret_cast<u32x2*>(base + 64) = part[1];
+}
+// the epilogues' image store: the descriptor's output format (bf16 with out_split_parts parts, or fp16 with out_split_scale)
+__device__ __forceinline__ void split_store4_out(const aldm_igemm_desc& d, void* img, int64_t row, int Cs, int c, const f32x4 v) {
+    if (d.out_split_fmt == ALDM_FMT_F16) split_store4_f16(img, row, Cs, c, v, d.out_split_scale);
+    else split_store4(img, row, Cs, c, v, d.out_split_parts);
+}
+
 // ... with the image format known at compile time: no `q < parts` branches around the stores, one split form compiled
 template <int P>
 __device__ __forceinline__ void split_store4_t(void* img, int64_t row, int Cs, int c, const f32x4 v) {
@@ -275,7 +289,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                     const int m = m0 + (wm * MT + i) * 32 + r;
                     if (m < p.M && cok && epi_st) {
                         if (go) *reinterpret_cast<f32x4*>(go + (int64_t)m * d.ldo + ncol_o) = xv;
-                        if (simg) split_store4(simg, m, d.out_split_c, ncol_o, xv, d.out_split_parts);
+                        if (simg) split_store4_out(d, simg, m, d.out_split_c, ncol_o, xv);
                     }
                 }
             }
@@ -385,7 +399,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
                 }
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
-                    if ((okmask >> it) & 1u) split_store4(simg, srow[it], simg_c, ncol - col_shift, v[it], d.out_split_parts);
+                    if ((okmask >> it) & 1u) {
+                        if (d.epi_mode == ALDM_EPI_QKV) split_store4(simg, srow[it], simg_c, ncol - col_shift, v[it], d.out_split_parts);
+                        else split_store4_out(d, simg, srow[it], simg_c, ncol - col_shift, v[it]);
+                    }
             }
         } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component
 #pragma unroll

@@ -82,6 +82,9 @@ def f16_mode() -> bool:
     return MMA_MODE == "f16x3"
 
 
+F16_FF_OUT = os.environ.get("ALDM_F16_FF_OUT", "1") != "0"   # A/B switch: the GEGLU output as an fp16 image (FF-out in f16x3 too)
+
+
 def _pow2_scale(bound: float) -> float:
     """The largest power of two s with s * bound <= 32768 (a factor two under fp16's 65504: the bound is mathematical, the slack
     covers fp32 rounding of the normalisation itself)."""
@@ -108,6 +111,22 @@ def _absmax_cached(t: Optional[torch.Tensor]) -> float:
     return c[1]
 
 
+def _row_norm_bound(gamma: torch.Tensor, beta: Optional[torch.Tensor], C: int) -> float:
+    """||gamma * x_hat + beta||_2 <= max|gamma| sqrt(C) + ||beta||_2 for a LayerNorm row (||x_hat||_2 <= sqrt(C))."""
+    import math
+    b2 = 0.0
+    if beta is not None:
+        c = getattr(beta, "_aldm_norm2", None)
+        if c is None or c[0] != beta._version:
+            c = (beta._version, float(beta.detach().double().norm()))
+            try:
+                beta._aldm_norm2 = c
+            except (AttributeError, RuntimeError):
+                pass
+        b2 = c[1]
+    return _absmax_cached(gamma) * math.sqrt(float(C)) + b2
+
+
 def _norm_f16_scale(gamma: torch.Tensor, beta: Optional[torch.Tensor], n: int) -> float:
     """fp16 image scale of a GroupNorm / LayerNorm output normalised over n elements: |gamma x_hat + beta| <= sqrt(n) max|gamma| +
     max|beta| (|x_hat| <= sqrt(n) holds for any data; SiLU only shrinks)."""
@@ -129,10 +148,23 @@ class Packed:
     split2: Optional[torch.Tensor] = None   # the 2-part ("bf16x3") image, DMA-fed launches only
     split16: Optional[torch.Tensor] = None  # the 2-part fp16 ("f16x3") image of w_scale * w
     w_scale: float = 0.0                    # ... its power-of-two scale
+    cmax: Optional[float] = None            # largest column 2-norm (out_bound)
+    bmax: float = 0.0
 
     @property
     def K(self) -> int:
         return self.KH * self.KW * self.Cin
+
+    def out_bound(self, rn: float) -> float:
+        """|x . w_n + b_n| <= rn * max_n ||w_n||_2 + max|b| for every row x with ||x||_2 <= rn (Cauchy-Schwarz); the weight's largest
+        column norm and bias are read once (host sync, before graph capture) and cached."""
+        if self.cmax is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("f16x3: a weight's column norms must be known before graph capture (run one eager step)")
+            npad = self.data.numel() // (4 * ((self.K + 3) // 4))
+            self.cmax = float(self.data.view(-1, npad, 4).double().pow(2).sum((0, 2)).max().sqrt())
+            self.bmax = 0.0 if self.bias is None else float(self.bias.abs().max())
+        return rn * self.cmax + self.bmax
 
     def split16_ptr(self) -> int:
         """Device pointer of the "f16x3" weight image (built on first use, before any graph capture): hi / lo fp16 of w_scale * w,
@@ -175,13 +207,15 @@ class Packed:
 class SplitT:
     """A split image (include/aldm_hip.h "split images"): the exact 3-way bf16 split of a channels-last fp32 tensor of
     logical shape `shape` = [..., C], stored [rows, C/32, 3, 32] as int16 — the pre-split A operand of the DMA-fed GEMM."""
-    __slots__ = ("data", "shape", "fmt", "scale")
+    __slots__ = ("data", "shape", "fmt", "scale", "rn")
 
-    def __init__(self, data: torch.Tensor, shape, fmt: str = "bf16", scale: float = 1.0):
+    def __init__(self, data: torch.Tensor, shape, fmt: str = "bf16", scale: float = 1.0, rn: float = 0.0):
         self.data = data
         self.shape = tuple(shape)
         self.fmt = fmt        # "bf16" | "f16" (the "f16x3" image: 2 parts, IEEE fp16, of scale * value)
         self.scale = scale
+        self.rn = rn          # a-priori bound of a ROW's 2-norm (LayerNorm outputs: sqrt(C) max|gamma| + ||beta||), 0 = unknown:
+                              # with it a projection's outputs are bounded by rn * (largest column norm of W) + max|bias|
 
     @property
     def parts(self) -> int:
@@ -221,7 +255,7 @@ class SplitT:
         tot = self.rows * self.C
         shape = tuple(tot // n if s_ == -1 else s_ for s_ in shape)
         assert shape[-1] == self.C, "a split image can only be re-viewed over its row dimensions"
-        return SplitT(self.data, shape, self.fmt, self.scale)
+        return SplitT(self.data, shape, self.fmt, self.scale, self.rn)
 
     def float(self) -> torch.Tensor:
         """hi + mid + lo back to fp32 (tests / debugging): exact for bf16 images; (hi + lo) / scale for an fp16 image."""
@@ -535,10 +569,19 @@ def linear_geglu(x, pw: Packed, split_out: Optional[str] = None, gate_act: int =
     assert shp[-1] == pw.Cin and pw.KH == 1 and pw.KW == 1 and pw.N % 64 == 0
     oshape = (*shp[:-1], pw.N // 2)
     out = None if split_out == "only" else torch.empty(oshape, device=x.device, dtype=torch.float32)
-    so = SplitT.empty(oshape, x.device) if split_out else None
+    so = None
+    if split_out:
+        if is_split and x.fmt == "f16" and x.rn > 0.0 and f16_mode() and F16_FF_OUT:
+            # "f16x3" all the way through the MLP: |value * gelu(gate)| <= |value| |gate| <= (rn c + b)^2 — the GEGLU output has an
+            # a-priori bound too, so it is written as an fp16 image and the FF-out GEMM runs three products as well
+            so = SplitT.empty(oshape, x.device, f16_scale=_pow2_scale(pw.out_bound(x.rn) ** 2))
+        else:
+            so = SplitT.empty(oshape, x.device)
     d = IgemmDesc()
     if is_split:
-        _set_split_operand(d, x, pw, so)
+        _set_split_operand(d, x, pw, so if (so is None or so.fmt == "bf16") else None)
+        if so is not None and so.fmt == "f16":
+            d.out_split_fmt = _l.FMT_F16; d.out_split_scale = so.scale
     else:
         d.x1 = x.data_ptr(); d.split_parts = 3
         d.w_split = pw.split_ptr(3)
@@ -863,6 +906,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         return y
     if f16_mode():
         so = SplitT.empty(x.shape, x.device, f16_scale=_norm_f16_scale(gamma, beta, Cc))
+        so.rn = _row_norm_bound(gamma, beta, Cc)
         _l.check(_l.load().aldm_layernorm_split_f16(x.data_ptr(), _p(y), so.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), eps,
                                                     so.scale, _stream()), "layernorm_split_f16")
         return so if split_out == "only" else (y, so)

@@ -184,6 +184,12 @@ typedef struct aldm_igemm_desc {
     int32_t a_fmt;
     float acc_scale;
     int32_t out_split_parts;
+    /* out_split_fmt = ALDM_FMT_F16: out_split (plain and GEGLU epilogues; not k_split / vt_split) is written as the 2-part fp16
+       image of out_split_scale * result — the A operand of a following f16x3 launch.  The caller vouches for |out_split_scale *
+       result| <= 65504 (e.g. the GEGLU output of a LayerNorm-fed projection: (R c + b)^2 with R the row 2-norm bound of the
+       normalised rows, c the largest column 2-norm of the weight, b the largest |bias|).                                  */
+    int32_t out_split_fmt;
+    float out_split_scale;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);

@@ -126,26 +126,44 @@ def test_layernorm_linear(ops, K, N, M, form):
     assert rel_err(y, ref) < fused_tol("f16x3")
 
 
-@pytest.mark.parametrize("C,M,form", [(256, 4096, None), (256, 4096, (32, 128, 303)), (384, 1024, (32, 128, 302)), (640, 256, None)])
-def test_layernorm_geglu(ops, C, M, form):
-    """LayerNorm -> GEGLU projection (attention.py:37-45) with the split-image output the FF-out GEMM reads: a 3-part bf16 image
-    written by a launch whose operands are fp16 images."""
+@pytest.mark.parametrize("C,M,form", [(256, 4096, None), (256, 4096, (32, 128, 303)), (384, 1024, (32, 128, 302)), (640, 256, None),
+                                      (640, 1024, (256, 128, 2))])
+def test_layernorm_geglu_ff_out(ops, C, M, form):
+    """LayerNorm -> GEGLU projection -> FF-out (attention.py:37-63), all three-product: the GEGLU output has an a-priori bound as
+    well — |value * gelu(gate)| <= |value| |gate| <= (R c + b)^2, R the LayerNorm rows' 2-norm bound, c the weight's largest column
+    norm — so the epilogue writes it as an fp16 image (operand-stationary and classic epilogues) and the FF-out GEMM reads that."""
     x = torch.randn(1, M, C, generator=g(1))
     ga, be = torch.randn(C, generator=g(2)) * 0.3 + 1.0, torch.randn(C, generator=g(3)) * 0.1
     w = torch.randn(8 * C, C, generator=g(4)) / math.sqrt(C)
     b = torch.randn(8 * C, generator=g(5)) * 0.5
+    w2 = torch.randn(C, 4 * C, generator=g(6)) / math.sqrt(4 * C)
+    b2 = torch.randn(C, generator=g(7))
     h = F.layer_norm(x, (C,), ga, be, 1e-5) @ w.double().t() + b.double()
     ref = h[..., :4 * C] * F.gelu(h[..., 4 * C:])
-    pw = ops.pack_geglu(w, b)
+    ref2 = ref @ w2.double().t() + b2.double() + x.double()
+    pw, pw2 = ops.pack_geglu(w, b), ops.pack_conv(w2, b2)
     n = ops.layernorm(x.cuda(), ga.cuda(), be.cuda(), 1e-5, split_out="only")
+    assert n.rn > 0.0
     if form:
         ops.igemm_force(form[0], form[1], 1, 0, form[2])
     try:
         y, so = ops.linear_geglu(n, pw, split_out="also")
     finally:
         ops.igemm_force(0, 0, 0)
-    assert so.fmt == "bf16" and so.parts == 3 and torch.equal(so.float(), y)
     assert rel_err(y, ref) < fused_tol("f16x3")
+    assert so.fmt == "f16" and so.parts == 2
+    assert float(so.scale) * float(ref.abs().max()) <= 32768.0          # the bound held
+    d = (so.float().double().cpu() - y.double().cpu()).abs()
+    assert bool((d <= y.double().cpu().abs() * 2.0 ** -21 + 2.0 ** -24 / so.scale).all())
+    y2 = ops.linear(so, pw2, res=x.cuda())
+    assert rel_err(y2, ref2) < fused_tol("f16x3")
+    # and with the switch off the image is the exact 3-part bf16 one
+    ops.F16_FF_OUT = False
+    try:
+        y3, so3 = ops.linear_geglu(n, pw, split_out="also")
+    finally:
+        ops.F16_FF_OUT = True
+    assert so3.fmt == "bf16" and so3.parts == 3 and torch.equal(so3.float(), y3)
 
 
 @pytest.mark.parametrize("B,L,heads,form", [(2, 256, 8, None), (2, 256, 8, (32, 128, 303)), (2, 128, 12, (32, 128, 302)), (1, 64, 20, None)])
