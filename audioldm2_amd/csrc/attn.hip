@@ -672,10 +672,22 @@ constexpr int item_slot(int k, int base) { return base + (k * S) / N; }
 // places of the schedule.  One s_barrier per key tile at the top of the body: behind it the pieces of tile j + 2 (issued NST - 3
 // tiles earlier, waited for with a counted vmcnt) are visible to every wave and the stage of tile j - 1 is free for tile
 // j + NST - 1.  Same arithmetic in the same order: bit-identical results.  Needs every wave of the block live (Lq % (128 QT) == 0).
-template <int QT, int NP, bool LDSKV = false>
+// F16 (round 6, the "f16x3" mode): K and V^T arrive as 2-part IEEE-fp16 images of k_scale * k and v_scale * v (the QKV epilogue
+// knows a bound of a LayerNorm-fed projection before the data: R c), q is split here into fp16 parts of q_mul * q (q_mul = softmax
+// scale * log2(e) * a power of two under the same bound), the probabilities into fp16 parts of 2^15 p, and both products run
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: 24 matrix instructions per key tile instead of 48.  The scores come out of the
+// accumulators in units of 1 / sc_c; the softmax reference is the INTEGER ceil(max score in log2 units) — so the exponent's offset
+// 15 - m and the rescale factor 2^(m_old - m_new) are exact — and everything the scalings multiplied in leaves with the final
+// out_mul / l.  (A softmax does not depend on its reference: any value >= the row maximum that keeps 2^15 p <= 65504 will do.)
+#ifndef ALDM_F16_POFF
+#define ALDM_F16_POFF 15.0f   // log2 of the factor the fp16 probabilities carry
+#endif
+template <int QT, int NP, bool LDSKV = false, bool F16 = false>
 __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     const float* __restrict__ q, const void* __restrict__ k_img, const void* __restrict__ vt_img, float* __restrict__ out,
-    int Lq, int Lk, int ldq, int heads, int ldo, float scale, void* __restrict__ out_split, int split_c, int parts) {
+    int Lq, int Lk, int ldq, int heads, int ldo, float scale, void* __restrict__ out_split, int split_c, int parts,
+    float q_mul = 0.f, float sc_c = 1.f, float out_mul = 1.f) {
+    static_assert(!F16 || NP == 2, "fp16 images have two parts");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int l31 = lane & 31;
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     constexpr int HALF = NMF / 2;         // ... the first HALF of them are k-step 0
 
     // Q^T operands, pre-scaled by scale * log2(e) (scores in log2 units), k-step s covers d = 16*lh + 8*s .. + 7
-    const float qscale = scale * 1.44269504088896340736f;
+    const float qscale = F16 ? q_mul : scale * 1.44269504088896340736f;
     bf16x8 qx[QT][2][3];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -707,7 +719,19 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
                 x8[e] = x0[e] * qscale;
                 x8[4 + e] = x1[e] * qscale;
             }
-            split8_np<NP>(x8, qx[t][s]);
+            if constexpr (F16) {
+                // (hi first, as a whole vector; the remainder from the converted-back hi: see item_sp below)
+                using f32x8 = float __attribute__((ext_vector_type(8)));
+                f32x8 xv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = x8[e];
+                const f16x8 hv = __builtin_convertvector(xv, f16x8);
+                const f16x8 lv = __builtin_convertvector(xv - __builtin_convertvector(hv, f32x8), f16x8);
+                qx[t][s][0] = __builtin_bit_cast(bf16x8, hv);
+                qx[t][s][1] = __builtin_bit_cast(bf16x8, lv);
+            } else {
+                split8_np<NP>(x8, qx[t][s]);
+            }
         }
     }
 
@@ -799,6 +823,18 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
             px[t][s][0][p] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
             px[t][s][1][p] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
             px[t][s][2][p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+        } else if constexpr (F16) {   // (hi, lo) fp16 parts of the (2^15-scaled) probabilities
+            // The low part MUST be the remainder of the hi that is stored: written with scalar conversions, hipcc packed the pair
+            // with v_cvt_pk_f16_f32 while it derived the remainder from a separate v_cvt_f16_f32 of the same input — and the two
+            // instructions do not round every input alike (2 of 4096 query rows came out 7e-5 off: one fp16 ulp of a hi part).
+            // Converting BACK from the packed value makes hi + lo exact whatever the instruction rounds to.
+            using f16x2 = _Float16 __attribute__((ext_vector_type(2)));
+            using f32x2 = float __attribute__((ext_vector_type(2)));
+            const f32x2 xx = {x0, x1};
+            const f16x2 hh = __builtin_convertvector(xx, f16x2);
+            const f16x2 ll = __builtin_convertvector(xx - __builtin_convertvector(hh, f32x2), f16x2);
+            px[t][s][0][p] = __builtin_bit_cast(unsigned, hh);
+            px[t][s][1][p] = __builtin_bit_cast(unsigned, ll);
         } else {   // (hi, mid) rounded to nearest: split8_rn2's arithmetic
             using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
             const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
@@ -825,9 +861,11 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
 #pragma unroll
             for (int r = 8; r < 16; ++r) mx = fmaxf(mx, S[P][t][r]);
             mx = max_across_halves(mx);
+            if constexpr (F16) mx = __builtin_ceilf(mx * sc_c);        // accumulator units -> log2 units, up to an integer (exact offsets)
             m_new[t] = fmaxf(m_run[t], mx);
             alpha[t] = __builtin_amdgcn_exp2f(m_run[t] - m_new[t]);   // 0 on the first tile (m_run = -inf)
             m_run[t] = m_new[t];
+            if constexpr (F16) m_new[t] = ALDM_F16_POFF - m_new[t];            // the exponent's offset: probabilities come out as 2^15 p
         }
     };
     // EX: probabilities 4g .. 4g + 3 of query tile t (in place) and their part of the row sum, in the scores' order
@@ -836,7 +874,8 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
         float ps = g == 0 ? 0.f : psum[t];
 #pragma unroll
         for (int r = 4 * g; r < 4 * g + 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(S[P][t][r] - m_new[t]);
+            const float pv = F16 ? __builtin_amdgcn_exp2f(__builtin_fmaf(S[P][t][r], sc_c, m_new[t]))
+                                 : __builtin_amdgcn_exp2f(S[P][t][r] - m_new[t]);
             S[P][t][r] = pv;
             ps += pv;
         }
@@ -849,15 +888,24 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
         constexpr int P = decltype(pc)::value;
         constexpr int i = decltype(ic)::value;
         constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
-        S[P][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Kr[P][s][PA_[pr]]), qx[t][s][PB_[pr]],
-                                                          (s == 0 && pr == 0) ? zero16 : S[P][t], 0, 0, 0);
+        if constexpr (F16)
+            S[P][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Kr[P][s][PA_[pr]]),
+                                                             __builtin_bit_cast(f16x8, qx[t][s][PB_[pr]]),
+                                                             (s == 0 && pr == 0) ? zero16 : S[P][t], 0, 0, 0);
+        else
+            S[P][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Kr[P][s][PA_[pr]]), qx[t][s][PB_[pr]],
+                                                              (s == 0 && pr == 0) ? zero16 : S[P][t], 0, 0, 0);
     };
     auto mfma_pv = [&](auto vc, auto ic) {   // vc: parity of the V tile (= of the P tile)
         constexpr int P = decltype(vc)::value;
         constexpr int i = decltype(ic)::value;
         constexpr int s = i / (NPROD * QT), pr = (i / QT) % NPROD, t = i % QT;
-        oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Vr[P][s][PA_[pr]]),
-                                                        __builtin_bit_cast(bf16x8, px[t][s][PB_[pr]]), oT[t], 0, 0, 0);
+        if constexpr (F16)
+            oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Vr[P][s][PA_[pr]]),
+                                                           __builtin_bit_cast(f16x8, px[t][s][PB_[pr]]), oT[t], 0, 0, 0);
+        else
+            oT[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Vr[P][s][PA_[pr]]),
+                                                            __builtin_bit_cast(bf16x8, px[t][s][PB_[pr]]), oT[t], 0, 0, 0);
     };
 
     // item lists of a steady-state tile j (parity P; Q = the other parity = tile j - 1), dealt evenly over the phase's MFMA slots:
@@ -976,7 +1024,7 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const float l_tot = l_run[t] + __shfl_xor(l_run[t], 32);
-        const float inv = 1.0f / l_tot;
+        const float inv = (F16 ? out_mul : 1.0f) / l_tot;   // (F16: O carries 2^15 v_scale, l carries 2^15)
         const int qi = q0 + 32 * t + l31;
         if (qi < Lq) {
             float* op = out ? out + ((int64_t)b * Lq + qi) * ldo + h * 32 + 4 * lh : nullptr;
@@ -1572,6 +1620,41 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
 #undef ALDM_ATTN_PRE2
 #undef ALDM_ATTN_PRE
     ALDM_LAUNCH_CHECK("aldm_attention_d32_presplit");
+    return 0;
+}
+
+// "f16x3" self-attention: K / V^T as 2-part fp16 images of k_scale * k, v_scale * v (ALDM_EPI_QKV with out_split_fmt = ALDM_FMT_F16),
+// q split in the kernel as fp16 parts of q_scale * softmax-scale * log2(e) * q; out_split (optional) stays a bf16 image with
+// out_parts parts.  Three matrix instructions per product in both contractions.
+extern "C" int aldm_attention_d32_presplit_f16(const float* q, const void* k_split, const void* vt_split, float* out, void* out_split,
+                                               int out_parts, int B, int heads, int Lq, int Lk, int ldq, int ldo, float scale,
+                                               float q_scale, float k_scale, float v_scale, void* stream) {
+    ALDM_CHECK(q && k_split && vt_split && (out || out_split), "aldm_attention_d32_presplit_f16: null pointer");
+    ALDM_CHECK(out_parts == 2 || out_parts == 3, "aldm_attention_d32_presplit_f16: out_parts must be 2 or 3");
+    ALDM_CHECK(q_scale > 0.f && k_scale > 0.f && v_scale > 0.f, "aldm_attention_d32_presplit_f16: scales must be positive");
+    ALDM_CHECK(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk % 32 == 0, "aldm_attention_d32_presplit_f16: Lk must be a multiple of 32");
+    if (!out) ldo = heads * 32;
+    ALDM_CHECK(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= heads * 32 && ldo >= heads * 32,
+               "aldm_attention_d32_presplit_f16: row pitches must be multiples of 4 and >= heads*32");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k_split) | reinterpret_cast<uintptr_t>(vt_split) |
+                 reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out_split)) & 15) == 0,
+               "aldm_attention_d32_presplit_f16: operands must be 16-byte aligned");
+    static const int env_qt = [] {
+        const char* e = getenv("ALDM_ATTN_QT");
+        return e ? atoi(e) : 0;
+    }();
+    const bool qt2 = env_qt ? env_qt == 2 : (Lq >= 128 && (int64_t)cdiv(Lq, 256) * heads * B >= 128);
+    dim3 grid(cdiv(Lq, qt2 ? 256 : 128), heads, B);
+    hipStream_t st = (hipStream_t)stream;
+    const float q_mul = scale * 1.44269504088896340736f * q_scale, sc_c = 1.0f / (q_scale * k_scale), out_mul = 1.0f / v_scale;
+    const int split_c = heads * 32;
+    if (qt2)
+        hipLaunchKernelGGL((attention_d32_presplit2_kernel<2, 2, false, true>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk,
+                           ldq, heads, ldo, scale, out_split, split_c, out_parts, q_mul, sc_c, out_mul);
+    else
+        hipLaunchKernelGGL((attention_d32_presplit2_kernel<1, 2, false, true>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk,
+                           ldq, heads, ldo, scale, out_split, split_c, out_parts, q_mul, sc_c, out_mul);
+    ALDM_LAUNCH_CHECK("aldm_attention_d32_presplit_f16");
     return 0;
 }
 

@@ -338,9 +338,10 @@ static int igemm_prepare(const aldm_igemm_desc* dd, IgemmK& p, int& BM, int& BN)
     ALDM_CHECK(d.a_fmt == ALDM_FMT_BF16 || (d.a_fmt == ALDM_FMT_F16 && d.a_split != nullptr && d.split_parts == 2 && d.acc_scale > 0.0f),
                "aldm_igemm: a_fmt = ALDM_FMT_F16 needs a pre-split operand (a_split), 2-part images and acc_scale > 0");
     if (d.a_fmt == ALDM_FMT_BF16) d.acc_scale = 1.0f;
-    ALDM_CHECK(d.out_split_fmt == ALDM_FMT_BF16 || (d.out_split_fmt == ALDM_FMT_F16 && d.out_split != nullptr && d.out_split_scale > 0.0f &&
-                                                   d.epi_mode != ALDM_EPI_QKV),
-               "aldm_igemm: out_split_fmt = ALDM_FMT_F16 needs out_split, out_split_scale > 0 and a plain or GEGLU epilogue");
+    ALDM_CHECK(d.out_split_fmt == ALDM_FMT_BF16 ||
+                   (d.out_split_fmt == ALDM_FMT_F16 && d.out_split_scale > 0.0f &&
+                    (d.epi_mode == ALDM_EPI_QKV ? (d.k_split != nullptr && d.vt_split != nullptr && d.vt_scale > 0.0f) : d.out_split != nullptr)),
+               "aldm_igemm: out_split_fmt = ALDM_FMT_F16 needs out_split (QKV: k_split, vt_split and vt_scale) and out_split_scale > 0");
     if (d.out_split_fmt == ALDM_FMT_F16) d.out_split_parts = 2;
     if (!d.x2) d.C2 = 0;
     if (d.pix1 == 0) d.pix1 = d.C1;

@@ -65,7 +65,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int ND = KT * NP / 4;            // LDS-DMA instructions per wave and stage (KT x 2 row groups x NP over 8 waves)
     static_assert(NP == 2 || NP == 3, "2 or 3 parts");
-    static_assert((NPO == 2 || NPO == 3) && (!F16 || NP == 2), "image formats");
+    static_assert((NPO == 2 || NPO == 3) && (!F16 || NP == 2) && (!FO || EPI != OS_EPI_QKV || NPO == 2), "image formats");
     static_assert(KT % 4 == 0 && KT >= 4, "the k-tiles of a stage are split between four wave pairs");
     static_assert(NST >= 2 && NST <= 4 && (NST - 2) * ND <= 63, "ring depth / vmcnt range");
     static_assert(os_lds_bytes(KT, NST, NP) <= 160 * 1024, "ring + staging must fit the CU's LDS");
@@ -269,7 +269,8 @@ void igemm_dma_os_kernel(const IgemmK p) {
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
                         u32x2 part[3];
-                        split4_parts(acc[rt], part, NPO);
+                        if constexpr (FO) split4_f16(acc[rt], d.vt_scale, part);
+                        else split4_parts(acc[rt], part, NPO);
 #pragma unroll
                         for (int q = 0; q < NPO; ++q) *reinterpret_cast<u32x2*>(base + q * 2048 + rt * 32) = part[q];
                     }
@@ -302,7 +303,7 @@ void igemm_dma_os_kernel(const IgemmK p) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[rt][c] = v[rt][c] > 0.0f ? v[rt][c] : v[rt][c] * d.out_split_slope;
                         }
-                        if constexpr (FO && EPI == OS_EPI_PLAIN) split_store4_f16(simg, m, simg_c, ncol - col_shift, v[rt], d.out_split_scale);
+                        if constexpr (FO) split_store4_f16(simg, m, simg_c, ncol - col_shift, v[rt], d.out_split_scale);
                         else split_store4_t<NPO>(simg, m, simg_c, ncol - col_shift, v[rt]);
                     }
                 }

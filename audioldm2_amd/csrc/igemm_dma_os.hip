@@ -22,10 +22,11 @@ int igemm_launch_dma_os(int KT, int nst, int parts, bool f16, dim3 grid, hipStre
     const int epi = p.d.epi_mode == ALDM_EPI_GEGLU ? OS_EPI_GEGLU : (p.d.epi_mode == ALDM_EPI_QKV ? OS_EPI_QKV : OS_EPI_PLAIN);
     if (f16) {   // "f16x3" operands (2 fp16 parts); the epilogue writes 3-part bf16 images (K / V^T, the GEGLU output)
         const bool fo = p.d.out_split_fmt == ALDM_FMT_F16;
-        if (parts != 2 || (!fo && p.d.out_split_parts != 3) || (fo && epi == OS_EPI_QKV)) return -1;
+        if (parts != 2 || (!fo && p.d.out_split_parts != 3)) return -1;
 #define ALDM_OS_H(KT_, NST_)                                                                                                   \
     if (KT == KT_ && nst == NST_) {                                                                                            \
         if (fo && epi == OS_EPI_GEGLU) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_GEGLU, 3, true, true>), grid, dim3(512), 0, st, p); \
+        else if (fo && epi == OS_EPI_QKV) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_QKV, 2, true, true>), grid, dim3(512), 0, st, p); \
         else if (fo) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_PLAIN, 3, true, true>), grid, dim3(512), 0, st, p); \
         else if (epi == OS_EPI_GEGLU) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_GEGLU, 3, true>), grid, dim3(512), 0, st, p); \
         else if (epi == OS_EPI_QKV) hipLaunchKernelGGL((igemm_dma_os_kernel<KT_, NST_, 2, OS_EPI_QKV, 3, true>), grid, dim3(512), 0, st, p); \

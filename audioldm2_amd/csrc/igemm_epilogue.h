@@ -238,7 +238,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
 #pragma unroll
                         for (int e = 0; e < 8; ++e) x8[e] = acc[i][j][8 * s + e];
                         u32x4 part[3];
-                        split8_to_parts(x8, part, parts);
+                        if (d.out_split_fmt == ALDM_FMT_F16) {
+                            f32x4 a = {x8[0], x8[1], x8[2], x8[3]}, bq = {x8[4], x8[5], x8[6], x8[7]};
+                            u32x2 pa[3], pb[3];
+                            split4_f16(a, d.vt_scale, pa);
+                            split4_f16(bq, d.vt_scale, pb);
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) part[q] = u32x4{pa[q][0], pa[q][1], pb[q][0], pb[q][1]};
+                        } else {
+                            split8_to_parts(x8, part, parts);
+                        }
 #pragma unroll
                         for (int q = 0; q < 3; ++q)
                             if (q < parts && epi_st) *reinterpret_cast<u32x4*>(base + q * 2048 + s * 32) = part[q];
@@ -400,8 +409,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmK& p, f32x16 (&acc)[MT
 #pragma unroll
                 for (int it = 0; it < ITC; ++it)
                     if ((okmask >> it) & 1u) {
-                        if (d.epi_mode == ALDM_EPI_QKV) split_store4(simg, srow[it], simg_c, ncol - col_shift, v[it], d.out_split_parts);
-                        else split_store4_out(d, simg, srow[it], simg_c, ncol - col_shift, v[it]);
+                        split_store4_out(d, simg, srow[it], simg_c, ncol - col_shift, v[it]);   // (QKV: the k image, scale out_split_scale)
                     }
             }
         } else {  // unaligned / ragged N (e.g. the 1-channel HiFi-GAN output conv): per component

@@ -50,7 +50,7 @@ class IgemmDesc(C.Structure):
         ("out_split_act", C.c_int32), ("out_split_slope", C.c_float),
         ("k_split", C.c_void_p), ("vt_split", C.c_void_p), ("qkv_c", C.c_int32), ("qkv_rows", C.c_int32),
         ("a_fmt", C.c_int32), ("acc_scale", C.c_float), ("out_split_parts", C.c_int32),
-        ("out_split_fmt", C.c_int32), ("out_split_scale", C.c_float),
+        ("out_split_fmt", C.c_int32), ("out_split_scale", C.c_float), ("vt_scale", C.c_float),
     ]
 
 
@@ -104,6 +104,9 @@ _SIGS = {
                                  C.c_float, C.c_void_p]),
     "aldm_attention_mma": (C.c_int, [C.c_int]),
     "aldm_attention_sched": (C.c_int, [C.c_int]),
+    "aldm_attention_d32_presplit_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                  C.c_float, C.c_void_p]),
     "aldm_attention_d32_presplit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

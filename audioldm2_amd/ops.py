@@ -83,6 +83,7 @@ def f16_mode() -> bool:
 
 
 F16_FF_OUT = os.environ.get("ALDM_F16_FF_OUT", "1") != "0"   # A/B switch: the GEGLU output as an fp16 image (FF-out in f16x3 too)
+F16_ATTN = os.environ.get("ALDM_F16_ATTN", "1") != "0"       # A/B switch: self-attention on fp16 K / V^T images (three products)
 
 
 def _pow2_scale(bound: float) -> float:
@@ -611,7 +612,11 @@ def linear_qkv(x: "SplitT", pw: Packed, heads: int, rows_per_sample: int):
     M = x.rows
     assert M % rows_per_sample == 0 and rows_per_sample % 32 == 0
     Bn = M // rows_per_sample
-    P = 3 if x.fmt == "f16" else x.parts   # the K / V^T images are bf16 (the attention runs bf16x6 behind f16x3 projections)
+    # "f16x3": q, k, v of a LayerNorm-fed projection are bounded by R c (R the rows' 2-norm bound, c the weight's largest column
+    # norm) — K and V^T are written as fp16 images under that bound and the attention runs three products too; without a bound
+    # (or with the switch off) they are 3-part bf16 images and the attention runs bf16x6 behind the f16x3 projection
+    f16_kv = x.fmt == "f16" and x.rn > 0.0 and f16_mode() and F16_ATTN
+    P = 2 if f16_kv else (3 if x.fmt == "f16" else x.parts)
     dev = x.device
     q = torch.empty((*x.shape[:-1], Cq), device=dev, dtype=torch.float32)
     k_img = torch.empty((M, heads, P, 32), device=dev, dtype=torch.int16)
@@ -619,6 +624,12 @@ def linear_qkv(x: "SplitT", pw: Packed, heads: int, rows_per_sample: int):
     d = IgemmDesc()
     _set_split_operand(d, x, pw)
     d.out_split_parts = P
+    if f16_kv:
+        bound = pw.out_bound(x.rn)
+        kv_scale = _pow2_scale(bound)
+        q_scale = _pow2_scale(bound * (32 ** -0.5) * 1.4426950408889634)
+        d.out_split_fmt = _l.FMT_F16; d.out_split_scale = kv_scale; d.vt_scale = kv_scale
+        k_img._aldm_f16 = (q_scale, kv_scale, kv_scale)
     d.C1 = pw.Cin; d.B = 1; d.H = 1; d.W = M; d.up_h = d.up_w = 1
     d.KH = d.KW = d.SH = d.SW = d.DH = d.DW = 1
     d.OH = 1; d.OW = M
@@ -642,14 +653,22 @@ def attention_presplit(q: torch.Tensor, k_img: torch.Tensor, vt_img: torch.Tenso
     if scale is None:
         scale = 32 ** -0.5
     out = None if split_out == "only" else torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
-    so = SplitT.empty((B, Lq, heads * 32), q.device, parts) if split_out else None
+    f16s = getattr(k_img, "_aldm_f16", None)
+    so = SplitT.empty((B, Lq, heads * 32), q.device, 3 if f16s is not None else parts) if split_out else None
     ev = None
     if ATTN_PROFILE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _l.check(_l.load().aldm_attention_d32_presplit(qp, k_img.data_ptr(), vt_img.data_ptr(), _p(out),
-                                                   None if so is None else so.data_ptr(), parts, B, heads, Lq, Lk, ldq,
-                                                   heads * 32, scale, _stream()), "attention_d32_presplit")
+    if f16s is not None:   # fp16 K / V^T images (linear_qkv in "f16x3" mode): three-product attention, q split under q_scale
+        assert abs(scale - 32 ** -0.5) < 1e-12, "the fp16 images' q scale was chosen for the default softmax scale"
+        _l.check(_l.load().aldm_attention_d32_presplit_f16(qp, k_img.data_ptr(), vt_img.data_ptr(), _p(out),
+                                                           None if so is None else so.data_ptr(), 3 if so is None else so.parts, B, heads,
+                                                           Lq, Lk, ldq, heads * 32, scale, f16s[0], f16s[1], f16s[2], _stream()),
+                 "attention_d32_presplit_f16")
+    else:
+        _l.check(_l.load().aldm_attention_d32_presplit(qp, k_img.data_ptr(), vt_img.data_ptr(), _p(out),
+                                                       None if so is None else so.data_ptr(), parts, B, heads, Lq, Lk, ldq,
+                                                       heads * 32, scale, _stream()), "attention_d32_presplit")
     if ev is not None:
         ev[1].record()
         ATTN_PROFILE.append((B, heads, Lq, Lk, False, 4.0 * B * heads * Lq * Lk * 32, ev[0], ev[1]))

@@ -190,6 +190,9 @@ typedef struct aldm_igemm_desc {
        normalised rows, c the largest column 2-norm of the weight, b the largest |bias|).                                  */
     int32_t out_split_fmt;
     float out_split_scale;
+    /* ALDM_EPI_QKV with out_split_fmt = ALDM_FMT_F16: k_split is the fp16 image of out_split_scale * k, vt_split of vt_scale * v
+       (aldm_attention_d32_presplit_f16 reads them)                                                                       */
+    float vt_scale;
 } aldm_igemm_desc;
 
 int aldm_igemm(const aldm_igemm_desc* d, void* stream);
@@ -348,6 +351,15 @@ int aldm_attention_mma(int mode);
  * reference per row (opt-in experiment, 1.7x the error), 3 = K / V^T tiles shared by a block's waves through LDS (ABI v9).
  * Returns the previous setting; other values only query.                                                                  */
 int aldm_attention_sched(int sched);
+/* "f16x3" self-attention (ABI v9): k_split / vt_split are the 2-part fp16 images an ALDM_EPI_QKV launch with out_split_fmt =
+ * ALDM_FMT_F16 wrote (of k_scale * k and v_scale * v); q is split in the kernel into fp16 parts of q_scale * scale * log2(e) * q
+ * (the caller vouches for |q_scale * scale * log2(e) * q| <= 65504: a LayerNorm-fed projection is bounded by R c), the
+ * probabilities into fp16 parts of 2^15 p; Q.K^T and P.V run hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (24 matrix
+ * instructions per 32-key tile and 64 queries instead of 48).  The softmax reference is the integer ceiling of the running
+ * maximum in log2 units, so its offsets are exact.  out_split (optional): a bf16 image with out_parts parts.            */
+int aldm_attention_d32_presplit_f16(const float* q, const void* k_split, const void* vt_split, float* out, void* out_split,
+                                    int out_parts, int B, int heads, int Lq, int Lk, int ldq, int ldo, float scale,
+                                    float q_scale, float k_scale, float v_scale, void* stream);
 /* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,
  * window_size = `window` <= 8, shared heads): per head h (channels [h*d, (h+1)*d), d <= 128)
  *   s[i, j] = (q_i/sqrt(d)).k_j + [|j-i| <= window] (q_i/sqrt(d)).emb_k[j-i+window];  s = -1e4 where mask_i*mask_j == 0;

@@ -166,29 +166,75 @@ def test_layernorm_geglu_ff_out(ops, C, M, form):
     assert so3.fmt == "bf16" and so3.parts == 3 and torch.equal(so3.float(), y3)
 
 
-@pytest.mark.parametrize("B,L,heads,form", [(2, 256, 8, None), (2, 256, 8, (32, 128, 303)), (2, 128, 12, (32, 128, 302)), (1, 64, 20, None)])
+@pytest.mark.parametrize("B,L,heads,form", [(2, 256, 8, None), (2, 256, 8, (32, 128, 303)), (2, 128, 12, (32, 128, 302)), (1, 64, 20, None),
+                                            (16, 1024, 8, None), (2, 96, 2, (64, 64, 3)), (1, 32, 2, (64, 64, 3))])
 def test_layernorm_qkv_attention(ops, B, L, heads, form):
-    """LayerNorm -> fused q | k | v projection (QKV epilogue: q fp32, K and V^T as 3-part bf16 images) -> self-attention, which
-    runs the six-product bf16 kernel behind the three-product fp16 projection."""
+    """LayerNorm -> fused q | k | v projection -> self-attention, three-product throughout: a LayerNorm-fed projection is bounded by
+    R c before the data exists, so the QKV epilogue (operand-stationary and classic) writes K and V^T as fp16 images of power-of-two
+    scaled values, the attention kernel splits q and the probabilities (x 2^15) into fp16 parts and runs both contractions on the
+    fp16 matrix instruction, with an integer softmax reference (exact offsets).  Checked against fp64 at the fused fp32-grade bar,
+    at 1, 2, 3 and many key tiles, 32 and 64 queries per wave; with ALDM_F16_ATTN off the images are 3-part bf16 and the attention
+    runs the six-product kernel behind the three-product projection."""
     C = heads * 32
     x = torch.randn(B, L, C, generator=g(1))
     ga, be = torch.randn(C, generator=g(2)) * 0.3 + 1.0, torch.randn(C, generator=g(3)) * 0.1
     wq, wk, wv = (torch.randn(C, C, generator=g(4 + i)) / math.sqrt(C) for i in range(3))
     pw = ops.pack_conv(torch.cat([wq, wk, wv], 0))
     n = ops.layernorm(x.cuda(), ga.cuda(), be.cuda(), 1e-5, split_out="only")
-    if form:
-        ops.igemm_force(form[0], form[1], 1, 0, form[2])
-    try:
-        q, kimg, vtimg = ops.linear_qkv(n, pw, heads, L)
-    finally:
-        ops.igemm_force(0, 0, 0)
-    assert kimg.shape[2] == 3 and vtimg.shape[3] == 3
-    a = ops.attention_presplit(q, kimg, vtimg, heads)
     xn = F.layer_norm(x, (C,), ga, be, 1e-5)
     sh = lambda t: t.view(B, L, heads, 32).transpose(1, 2)
-    ref = F.scaled_dot_product_attention(sh(xn @ wq.double().t()), sh(xn @ wk.double().t()), sh(xn @ wv.double().t()))
-    assert rel_err(q, xn @ wq.double().t()) < fused_tol("f16x3")
-    assert rel_err(a, ref.transpose(1, 2).reshape(B, L, C)) < fused_tol("f16x3")
+    qd, kd, vd = xn @ wq.double().t(), xn @ wk.double().t(), xn @ wv.double().t()
+    ref = F.scaled_dot_product_attention(sh(qd), sh(kd), sh(vd)).transpose(1, 2).reshape(B, L, C)
+    for f16_attn in (True, False):
+        ops.F16_ATTN = f16_attn
+        try:
+            if form:
+                ops.igemm_force(form[0], form[1], 1, 0, form[2])
+            try:
+                q, kimg, vtimg = ops.linear_qkv(n, pw, heads, L)
+            finally:
+                ops.igemm_force(0, 0, 0)
+            assert kimg.shape[2] == (2 if f16_attn else 3) and vtimg.shape[3] == kimg.shape[2]
+            a, so = ops.attention_presplit(q, kimg, vtimg, heads, split_out="also")
+        finally:
+            ops.F16_ATTN = True
+        if f16_attn:
+            qs, ks, vs = kimg._aldm_f16
+            assert float(kd.abs().max()) * ks <= 32768.0 and float(vd.abs().max()) * vs <= 32768.0      # the bounds held
+            assert float(qd.abs().max()) * (32 ** -0.5) * 1.4426950408889634 * qs <= 32768.0
+            kf = kimg.view(torch.float16).float()
+            kf = ((kf[:, :, 0] + kf[:, :, 1]) / ks).reshape(B, L, C)
+            assert rel_err(kf, kd) < fused_tol("f16x3")
+        assert so.fmt == "bf16" and so.parts == 3 and torch.equal(so.float(), a)
+        assert rel_err(q, qd) < fused_tol("f16x3")
+        assert rel_err(a, ref) < fused_tol("f16x3")
+
+
+def test_f16_attention_survives_extreme_scores(ops):
+    """Scores hundreds of log2 units apart, arriving in later key tiles: the integer softmax reference follows the running maximum
+    (rescale factors are exact powers of two), nothing overflows the 2^15-scaled fp16 probabilities, outputs stay finite and
+    within the fused bar plus the score-rounding allowance of the six-product kernel's own test."""
+    B, L, heads = 2, 128, 2
+    C = heads * 32
+    x = torch.randn(B, L, C, generator=g(1))
+    ga, be = torch.ones(C), torch.zeros(C)
+    wq, wk, wv = (torch.randn(C, C, generator=g(4 + i)) / math.sqrt(C) for i in range(3))
+    wq = wq * 12.0
+    wk = wk * 12.0     # scores ~ N(0, 144 * ...) in natural units: hundreds of log2 units between keys
+    pw = ops.pack_conv(torch.cat([wq, wk, wv], 0))
+    n = ops.layernorm(x.cuda(), ga.cuda(), be.cuda(), 1e-5, split_out="only")
+    q, kimg, vtimg = ops.linear_qkv(n, pw, heads, L)
+    assert kimg.shape[2] == 2
+    a = ops.attention_presplit(q, kimg, vtimg, heads)
+    assert bool(torch.isfinite(a).all())
+    xn = F.layer_norm(x, (C,), ga, be, 1e-5)
+    sh = lambda t: t.view(B, L, heads, 32).transpose(1, 2)
+    qd, kd, vd = sh(xn @ wq.double().t()), sh(xn @ wk.double().t()), sh(xn @ wv.double().t())
+    sc = qd @ kd.transpose(-1, -2) / math.sqrt(32.0)
+    ref = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B, L, C)
+    smax = float(sc.abs().max())
+    assert smax > 100.0
+    assert rel_err(a, ref) < fused_tol("f16x3") + 2.0 ** -24 * smax * 1.4426950408889634
 
 
 @pytest.mark.parametrize("gain,offset,wkind", [(1e-3, 0.0, "normal"), (50.0, 10.0, "normal"), (1.0, 0.0, "t3"), (1.0, 0.0, "tiny"),
