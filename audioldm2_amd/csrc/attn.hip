@@ -686,7 +686,7 @@ template <int QT, int NP, bool LDSKV = false, bool F16 = false>
 __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
     const float* __restrict__ q, const void* __restrict__ k_img, const void* __restrict__ vt_img, float* __restrict__ out,
     int Lq, int Lk, int ldq, int heads, int ldo, float scale, void* __restrict__ out_split, int split_c, int parts,
-    float q_mul = 0.f, float sc_c = 1.f, float out_mul = 1.f) {
+    float q_mul = 0.f, float sc_c = 1.f, float out_mul = 1.f, float out_img_scale = 0.f) {
     static_assert(!F16 || NP == 2, "fp16 images have two parts");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1034,7 +1034,14 @@ __global__ __launch_bounds__(256) void attention_d32_presplit2_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = oT[t][4 * g + e] * inv;
                 if (op) *reinterpret_cast<f32x4*>(op + 8 * g) = x;
-                if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
+                if constexpr (F16) {   // (a convex combination of the values: |out| <= max|v|, the image may carry v's scale)
+                    if (out_split && out_img_scale != 0.f)
+                        split_store4_f16(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, out_img_scale);
+                    else if (out_split)
+                        split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
+                } else {
+                    if (out_split) split_store4(out_split, (int64_t)b * Lq + qi, split_c, h * 32 + 8 * g + 4 * lh, x, parts);
+                }
             }
         }
     }
@@ -1624,13 +1631,17 @@ extern "C" int aldm_attention_d32_presplit(const float* q, const void* k_split, 
 }
 
 // "f16x3" self-attention: K / V^T as 2-part fp16 images of k_scale * k, v_scale * v (ALDM_EPI_QKV with out_split_fmt = ALDM_FMT_F16),
-// q split in the kernel as fp16 parts of q_scale * softmax-scale * log2(e) * q; out_split (optional) stays a bf16 image with
-// out_parts parts.  Three matrix instructions per product in both contractions.
+// q split in the kernel as fp16 parts of q_scale * softmax-scale * log2(e) * q; out_split (optional) is a bf16 image with
+// out_parts parts, or — out_parts = 0 — the 2-part fp16 image of out_scale * out (the output is a convex combination of the
+// values: out_scale = v_scale keeps it inside fp16 whenever the V image is).  Three matrix instructions per product in both
+// contractions.
 extern "C" int aldm_attention_d32_presplit_f16(const float* q, const void* k_split, const void* vt_split, float* out, void* out_split,
-                                               int out_parts, int B, int heads, int Lq, int Lk, int ldq, int ldo, float scale,
-                                               float q_scale, float k_scale, float v_scale, void* stream) {
+                                               int out_parts, float out_scale, int B, int heads, int Lq, int Lk, int ldq, int ldo,
+                                               float scale, float q_scale, float k_scale, float v_scale, void* stream) {
     ALDM_CHECK(q && k_split && vt_split && (out || out_split), "aldm_attention_d32_presplit_f16: null pointer");
-    ALDM_CHECK(out_parts == 2 || out_parts == 3, "aldm_attention_d32_presplit_f16: out_parts must be 2 or 3");
+    ALDM_CHECK(out_parts == 2 || out_parts == 3 || (out_parts == 0 && out_scale > 0.f),
+               "aldm_attention_d32_presplit_f16: out_parts must be 2 or 3 (bf16 image) or 0 with out_scale > 0 (fp16 image)");
+    const float out_img_scale = out_parts == 0 ? out_scale : 0.f;
     ALDM_CHECK(q_scale > 0.f && k_scale > 0.f && v_scale > 0.f, "aldm_attention_d32_presplit_f16: scales must be positive");
     ALDM_CHECK(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk % 32 == 0, "aldm_attention_d32_presplit_f16: Lk must be a multiple of 32");
     if (!out) ldo = heads * 32;
@@ -1650,10 +1661,10 @@ extern "C" int aldm_attention_d32_presplit_f16(const float* q, const void* k_spl
     const int split_c = heads * 32;
     if (qt2)
         hipLaunchKernelGGL((attention_d32_presplit2_kernel<2, 2, false, true>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk,
-                           ldq, heads, ldo, scale, out_split, split_c, out_parts, q_mul, sc_c, out_mul);
+                           ldq, heads, ldo, scale, out_split, split_c, out_parts, q_mul, sc_c, out_mul, out_img_scale);
     else
         hipLaunchKernelGGL((attention_d32_presplit2_kernel<1, 2, false, true>), grid, dim3(256), 0, st, q, k_split, vt_split, out, Lq, Lk,
-                           ldq, heads, ldo, scale, out_split, split_c, out_parts, q_mul, sc_c, out_mul);
+                           ldq, heads, ldo, scale, out_split, split_c, out_parts, q_mul, sc_c, out_mul, out_img_scale);
     ALDM_LAUNCH_CHECK("aldm_attention_d32_presplit_f16");
     return 0;
 }

@@ -104,9 +104,9 @@ _SIGS = {
                                  C.c_float, C.c_void_p]),
     "aldm_attention_mma": (C.c_int, [C.c_int]),
     "aldm_attention_sched": (C.c_int, [C.c_int]),
-    "aldm_attention_d32_presplit_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
-                                                  C.c_float, C.c_void_p]),
+    "aldm_attention_d32_presplit_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                  C.c_float, C.c_float, C.c_void_p]),
     "aldm_attention_d32_presplit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "aldm_attention_d32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -84,6 +84,7 @@ def f16_mode() -> bool:
 
 F16_FF_OUT = os.environ.get("ALDM_F16_FF_OUT", "1") != "0"   # A/B switch: the GEGLU output as an fp16 image (FF-out in f16x3 too)
 F16_ATTN = os.environ.get("ALDM_F16_ATTN", "1") != "0"       # A/B switch: self-attention on fp16 K / V^T images (three products)
+F16_ATTN_OUT = os.environ.get("ALDM_F16_ATTN_OUT", "1") != "0"   # A/B switch: that attention's output as an fp16 image (to_out in f16x3)
 
 
 def _pow2_scale(bound: float) -> float:
@@ -654,7 +655,13 @@ def attention_presplit(q: torch.Tensor, k_img: torch.Tensor, vt_img: torch.Tenso
         scale = 32 ** -0.5
     out = None if split_out == "only" else torch.empty((B, Lq, heads * 32), device=q.device, dtype=torch.float32)
     f16s = getattr(k_img, "_aldm_f16", None)
-    so = SplitT.empty((B, Lq, heads * 32), q.device, 3 if f16s is not None else parts) if split_out else None
+    # fp16 K / V^T images: the output is a convex combination of the values (|out| <= max|v|), so its image can be an fp16 one
+    # under V's scale and the to_out projection runs three products too (ALDM_F16_ATTN_OUT=0: a 3-part bf16 image, six products)
+    f16_out = f16s is not None and F16_ATTN_OUT
+    so = None
+    if split_out:
+        so = SplitT.empty((B, Lq, heads * 32), q.device, f16_scale=f16s[2]) if f16_out else \
+            SplitT.empty((B, Lq, heads * 32), q.device, 3 if f16s is not None else parts)
     ev = None
     if ATTN_PROFILE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -662,7 +669,9 @@ def attention_presplit(q: torch.Tensor, k_img: torch.Tensor, vt_img: torch.Tenso
     if f16s is not None:   # fp16 K / V^T images (linear_qkv in "f16x3" mode): three-product attention, q split under q_scale
         assert abs(scale - 32 ** -0.5) < 1e-12, "the fp16 images' q scale was chosen for the default softmax scale"
         _l.check(_l.load().aldm_attention_d32_presplit_f16(qp, k_img.data_ptr(), vt_img.data_ptr(), _p(out),
-                                                           None if so is None else so.data_ptr(), 3 if so is None else so.parts, B, heads,
+                                                           None if so is None else so.data_ptr(),
+                                                           3 if so is None else (0 if so.fmt == "f16" else so.parts),
+                                                           0.0 if so is None or so.fmt != "f16" else so.scale, B, heads,
                                                            Lq, Lk, ldq, heads * 32, scale, f16s[0], f16s[1], f16s[2], _stream()),
                  "attention_d32_presplit_f16")
     else:

@@ -356,10 +356,12 @@ int aldm_attention_sched(int sched);
  * (the caller vouches for |q_scale * scale * log2(e) * q| <= 65504: a LayerNorm-fed projection is bounded by R c), the
  * probabilities into fp16 parts of 2^15 p; Q.K^T and P.V run hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (24 matrix
  * instructions per 32-key tile and 64 queries instead of 48).  The softmax reference is the integer ceiling of the running
- * maximum in log2 units, so its offsets are exact.  out_split (optional): a bf16 image with out_parts parts.            */
+ * maximum in log2 units, so its offsets are exact.  out_split (optional): a bf16 image with out_parts (2 | 3) parts, or with
+ * out_parts = 0 the 2-part fp16 image of out_scale * out (|out| <= max|v|: out_scale = v_scale is always safe) — the operand
+ * of a three-product to_out projection.                                                                                   */
 int aldm_attention_d32_presplit_f16(const float* q, const void* k_split, const void* vt_split, float* out, void* out_split,
-                                    int out_parts, int B, int heads, int Lq, int Lk, int ldq, int ldo, float scale,
-                                    float q_scale, float k_scale, float v_scale, void* stream);
+                                    int out_parts, float out_scale, int B, int heads, int Lq, int Lk, int ldq, int ldo,
+                                    float scale, float q_scale, float k_scale, float v_scale, void* stream);
 /* Windowed relative-position self-attention of the VITS phoneme encoder (phoneme_encoder/attentions.py:239-289,
  * window_size = `window` <= 8, shared heads): per head h (channels [h*d, (h+1)*d), d <= 128)
  *   s[i, j] = (q_i/sqrt(d)).k_j + [|j-i| <= window] (q_i/sqrt(d)).emb_k[j-i+window];  s = -1e4 where mask_i*mask_j == 0;

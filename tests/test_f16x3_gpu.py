@@ -205,9 +205,17 @@ def test_layernorm_qkv_attention(ops, B, L, heads, form):
             kf = kimg.view(torch.float16).float()
             kf = ((kf[:, :, 0] + kf[:, :, 1]) / ks).reshape(B, L, C)
             assert rel_err(kf, kd) < fused_tol("f16x3")
-        assert so.fmt == "bf16" and so.parts == 3 and torch.equal(so.float(), a)
+        if f16_attn:   # the output image is an fp16 one under V's scale (a convex combination of the values cannot exceed them)
+            assert so.fmt == "f16" and so.scale == vs and float(ref.abs().max()) * vs <= 32768.0
+            assert rel_err(so.float(), a.double()) < 2.0 ** -21
+        else:
+            assert so.fmt == "bf16" and so.parts == 3 and torch.equal(so.float(), a)
         assert rel_err(q, qd) < fused_tol("f16x3")
         assert rel_err(a, ref) < fused_tol("f16x3")
+        # ... and the to_out projection (+ bias + residual) consumes it: three products behind the fp16 attention, six otherwise
+        wo, bo = torch.randn(C, C, generator=g(9)) / math.sqrt(C), torch.randn(C, generator=g(10)) * 0.1
+        y = ops.linear(so, ops.pack_conv(wo, bo), res=x.cuda())
+        assert rel_err(y, ref @ wo.double().t() + bo.double() + x.double()) < fused_tol("f16x3")
 
 
 def test_f16_attention_survives_extreme_scores(ops):
