@@ -197,7 +197,9 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const float* __r
                                                                 const int64_t* __restrict__ pos_ptr,
                                                                 float* __restrict__ kc, float* __restrict__ vc,
                                                                 const float* __restrict__ keymask, int n_tot, int heads,
-                                                                float scale, float* __restrict__ out, int ldo) {
+                                                                float scale, float* __restrict__ out, int ldo,
+                                                                int qparts = 1, int64_t qstride = 0,
+                                                                const float* __restrict__ qbias = nullptr) {
     __shared__ __attribute__((aligned(16))) float sq[64], sk[64], sv[64];
     __shared__ float sp[1024];
     __shared__ float red_max[16], red_sum[16];
@@ -224,7 +226,17 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const float* __r
     }
     if (tid < 64) {
         const float* r = qkv + (int64_t)b * ldq + h * 64 + tid;
-        const float q = r[0], k = r[E], v = r[2 * E];
+        float q = r[0], k = r[E], v = r[2 * E];
+        for (int j = 1; j < qparts; ++j) {   // (round 6) c_attn's K-slices, summed in slab order, then its bias
+            q += r[j * qstride];
+            k += r[j * qstride + E];
+            v += r[j * qstride + 2 * E];
+        }
+        if (qbias) {
+            q += qbias[h * 64 + tid];
+            k += qbias[E + h * 64 + tid];
+            v += qbias[2 * E + h * 64 + tid];
+        }
         sq[tid] = q;
         sk[tid] = k;
         sv[tid] = v;
@@ -306,6 +318,147 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const float* __r
     }
 }
 
+
+// ---- round 6: the same decode step on the WHOLE chip --------------------------------------------------------------------------
+// decode_linear_kernel gives one block all of K for its 32 columns: 24 - 96 blocks per launch, each pulling 96 - 393 KB of weights
+// through ONE compute unit's memory path (tens of GB/s per CU) — 8 us per 1024-row pass whatever the HBM could deliver, 24.7 us
+// for m_proj.  A dependent kernel boundary costs ~1.5 us on this chip (MI355X_MICROARCH.md, row "boundary"), far less than that:
+// so the layer is cut into MORE launches that each use every CU for one HBM round trip:
+//   decode_gemv_kernel       a block = 32 columns x ONE K-slice of R <= 512 rows (<= 64 KB of weights, all in flight at once,
+//                            non-temporal: each byte is read once per token), grid = column tiles x K-slices ~ 288 blocks; writes
+//                            the slice's partial sums ypart[slice][m][n].  Its activations are read as act(bias + sum of the
+//                            PREVIOUS launch's partial slabs) — that is how m_proj consumes c_fc without a launch in between.
+//   decode_reduce_ln_kernel  one block per row: h = res + bias + sum of the partial slabs in slab order (deterministic), and the
+//                            LayerNorm of the result for the next GEMV (mean, then the centred second moment, like aldm_layernorm).
+//   decode_attention_kernel  takes q | k | v as bias + sum of c_attn's partial slabs.
+// 7 launches per GPT-2 block instead of 5, each a fraction of the old ones' time.
+constexpr int DG_CT = 32;        // output columns per block
+constexpr int DG_WAVES = 4;
+constexpr int DG_MAXR = 512;     // rows per K-slice: 8 row groups x <= 64 rows in flight per lane
+constexpr int DG_NL = DG_MAXR / (2 * DG_WAVES);
+
+template <int MT>
+__global__ __launch_bounds__(256) void decode_gemv_kernel(const float* __restrict__ x, int ldx, int xparts, int64_t xstride,
+                                                          const float* __restrict__ xbias, int xact, int M, int K,
+                                                          const float* __restrict__ W, int N, float* __restrict__ ypart, int R) {
+    __shared__ __attribute__((aligned(16))) float xs[MT][DG_MAXR];
+    __shared__ float red[DG_WAVES][MT][DG_CT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane >> 5, c = lane & 31;
+    const int col = blockIdx.x * DG_CT + c;
+    const bool col_ok = col < N;
+    const int k0 = blockIdx.y * R;
+    const int nl = R / (2 * DG_WAVES);            // rows per lane: a multiple of 4
+    const int kb = (2 * w + sub) * nl;
+    // (1) the slice's weights: every row segment of this lane in flight before anything else
+    const float* wp = W + (int64_t)(k0 + kb) * N + (col_ok ? col : 0);
+    float wv[DG_NL];
+#pragma unroll
+    for (int g = 0; g < DG_NL / 4; ++g) {
+        if (4 * g < nl) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[4 * g + i] = __builtin_nontemporal_load(wp + (int64_t)(4 * g + i) * N);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[4 * g + i] = 0.f;
+        }
+    }
+    // (2) the slice of the activations -> LDS: plain rows, or act(bias + the previous launch's partial slabs in slab order)
+    for (int t = tid; t < R; t += DG_WAVES * 64) {
+        const int k = k0 + t;
+        float xv[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xv[m] = m < M ? x[(int64_t)m * ldx + k] : 0.f;
+        for (int j = 1; j < xparts; ++j) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xv[m] += m < M ? x[j * xstride + (int64_t)m * ldx + k] : 0.f;
+        }
+        const float b = xbias ? xbias[k] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xs[m][t] = m < M ? act_apply(xv[m] + b, xact, 0.f) : 0.f;
+    }
+    lds_sync();
+    // (3) FMAs in ascending k
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+#pragma unroll
+    for (int g = 0; g < DG_NL / 4; ++g) {
+        if (4 * g < nl) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[m][kb + 4 * g]);
+                acc[m] = fmaf(xv[0], wv[4 * g + 0], acc[m]);
+                acc[m] = fmaf(xv[1], wv[4 * g + 1], acc[m]);
+                acc[m] = fmaf(xv[2], wv[4 * g + 2], acc[m]);
+                acc[m] = fmaf(xv[3], wv[4 * g + 3], acc[m]);
+            }
+        }
+    }
+    // (4) the two row groups of a wave, then the four waves in wave order
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] += __shfl_xor(acc[m], 32);
+    if (lane < DG_CT) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) red[w][m][c] = acc[m];
+    }
+    lds_sync();
+    for (int t = tid; t < MT * DG_CT; t += DG_WAVES * 64) {
+        const int m = t / DG_CT, cc = t % DG_CT;
+        const int ocol = blockIdx.x * DG_CT + cc;
+        if (m < M && ocol < N) {
+            float v = red[0][m][cc];
+#pragma unroll
+            for (int i = 1; i < DG_WAVES; ++i) v += red[i][m][cc];
+            ypart[((int64_t)blockIdx.y * M + m) * N + ocol] = v;
+        }
+    }
+}
+
+// One block per row m: v = part[0][m] + part[1][m] + ... (slab order), + bias (row *bias_row of a table when bias_row != null:
+// the position embedding), + res; h_out = v (may alias res); xn = LayerNorm(v) gamma + beta when ln_g.  N <= 1024, N % 4 == 0.
+__global__ __launch_bounds__(256) void decode_reduce_ln_kernel(const float* __restrict__ part, int nparts, int64_t pstride, int ldp,
+                                                               const float* __restrict__ bias, const int64_t* __restrict__ bias_row,
+                                                               const float* __restrict__ res, int ldr, int N,
+                                                               float* __restrict__ h_out, int ldh,
+                                                               const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
+                                                               float* __restrict__ xn, int ldn, float* __restrict__ xn2, int ldn2) {
+    __shared__ float s_red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c4 = tid * 4;
+    const bool on = c4 < N;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        if (nparts > 0) v = *reinterpret_cast<const f32x4*>(part + (int64_t)m * ldp + c4);
+        for (int j = 1; j < nparts; ++j) v += *reinterpret_cast<const f32x4*>(part + j * pstride + (int64_t)m * ldp + c4);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + (bias_row ? *bias_row * (int64_t)N : 0) + c4);
+        if (res) v += *reinterpret_cast<const f32x4*>(res + (int64_t)m * ldr + c4);
+        if (h_out) *reinterpret_cast<f32x4*>(h_out + (int64_t)m * ldh + c4) = v;
+    }
+    if (!ln_g) return;
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) s_red[w] = s;
+    __syncthreads();
+    const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)N;
+    __syncthreads();
+    const f32x4 d = v - mean;
+    float q = on ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) s_red[w] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)N + eps);
+    if (on) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(ln_g + c4), b = *reinterpret_cast<const f32x4*>(ln_b + c4);
+        const f32x4 y = d * rstd * g + b;
+        *reinterpret_cast<f32x4*>(xn + (int64_t)m * ldn + c4) = y;
+        if (xn2) *reinterpret_cast<f32x4*>(xn2 + (int64_t)m * ldn2 + c4) = y;
+    }
+}
+
 }  // namespace aldm
 
 using namespace aldm;
@@ -355,5 +508,78 @@ extern "C" int aldm_decode_attention(const float* qkv, int ldq, const int64_t* p
     hipLaunchKernelGGL(decode_attention_kernel, dim3(B * heads), dim3(1024), 0, (hipStream_t)stream, qkv, ldq, pos, k_cache,
                        v_cache, keymask, n_tot, heads, scale, out, ldo);
     ALDM_LAUNCH_CHECK("aldm_decode_attention");
+    return 0;
+}
+
+// ---- round 6: split-K decode step (7 launches per GPT-2 block, every one on the whole chip) ----
+static int decode_gemv_slices(int K, int N) {
+    // K-slices: enough blocks to cover the chip (~288), slices of R = K / S rows with R % 32 == 0 and R <= DG_MAXR
+    const int tiles = cdiv(N, DG_CT);
+    int best = 0;
+    for (int S = 1; S <= 64; ++S) {
+        if (K % S) continue;
+        const int R = K / S;
+        if (R % 32 || R > DG_MAXR) continue;
+        best = S;
+        if (tiles * S >= 256) break;
+    }
+    return best;
+}
+
+extern "C" int aldm_decode_gemv_slices(int K, int N) { return decode_gemv_slices(K, N); }
+
+extern "C" int aldm_decode_gemv(const float* x, int ldx, int xparts, int64_t xstride, const float* xbias, int xact, int M, int K,
+                                const float* w_kn, int N, float* ypart, void* stream) {
+    ALDM_CHECK(x && w_kn && ypart && M > 0 && M <= DL_MAXM && K > 0 && N > 0, "aldm_decode_gemv: bad args (1 <= M <= %d rows)", DL_MAXM);
+    ALDM_CHECK(xparts >= 1 && ldx >= K, "aldm_decode_gemv: xparts >= 1, row pitch >= K");
+    ALDM_CHECK(xact == ALDM_ACT_NONE || xact == ALDM_ACT_GELU || xact == ALDM_ACT_GELU_TANH || xact == ALDM_ACT_SILU || xact == ALDM_ACT_TANH,
+               "aldm_decode_gemv: unsupported activation %d", xact);
+    const int S = decode_gemv_slices(K, N);
+    ALDM_CHECK(S > 0, "aldm_decode_gemv: K = %d has no slicing into multiples of 32 rows of at most %d", K, DG_MAXR);
+    const int MT = M <= 4 ? 4 : M <= 8 ? 8 : 16;
+    const dim3 grid(cdiv(N, DG_CT), S);
+#define ALDM_DG(MT_)                                                                                                          \
+    hipLaunchKernelGGL((decode_gemv_kernel<MT_>), grid, dim3(DG_WAVES * 64), 0, (hipStream_t)stream, x, ldx, xparts, xstride, xbias, \
+                       xact, M, K, w_kn, N, ypart, K / S)
+    switch (MT) {
+        case 4: ALDM_DG(4); break;
+        case 8: ALDM_DG(8); break;
+        default: ALDM_DG(16); break;
+    }
+#undef ALDM_DG
+    ALDM_LAUNCH_CHECK("aldm_decode_gemv");
+    return 0;
+}
+
+extern "C" int aldm_decode_reduce_ln(const float* part, int nparts, int64_t pstride, int ldp, const float* bias, const int64_t* bias_row,
+                                     const float* res, int ldr, int M, int N, float* h_out, int ldh, const float* ln_gamma,
+                                     const float* ln_beta, float ln_eps, float* xn, int ldn, float* xn2, int ldn2, void* stream) {
+    ALDM_CHECK(M > 0 && N > 0 && N <= 1024 && N % 4 == 0, "aldm_decode_reduce_ln: 1 <= N <= 1024, N %% 4 == 0");
+    ALDM_CHECK(nparts >= 0 && (nparts == 0 || part) && (h_out || ln_gamma), "aldm_decode_reduce_ln: bad args");
+    ALDM_CHECK(!ln_gamma == !ln_beta && (!ln_gamma || xn), "aldm_decode_reduce_ln: LayerNorm needs gamma, beta and an output");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(res) |
+                 reinterpret_cast<uintptr_t>(h_out) | reinterpret_cast<uintptr_t>(xn) | reinterpret_cast<uintptr_t>(xn2) |
+                 reinterpret_cast<uintptr_t>(ln_gamma) | reinterpret_cast<uintptr_t>(ln_beta)) & 15) == 0 &&
+                   ((ldp | ldr | ldh | ldn | ldn2 | (int)(pstride & 3)) & 3) == 0,
+               "aldm_decode_reduce_ln: operands must be 16-byte aligned with pitches that are multiples of 4");
+    hipLaunchKernelGGL(decode_reduce_ln_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, part, nparts, pstride, ldp, bias, bias_row,
+                       res, ldr, N, h_out, ldh, ln_gamma, ln_beta, ln_eps, xn, ldn, xn2, ldn2);
+    ALDM_LAUNCH_CHECK("aldm_decode_reduce_ln");
+    return 0;
+}
+
+extern "C" int aldm_decode_attention_parts(const float* qkv_part, int ldq, int qparts, int64_t qstride, const float* qbias,
+                                           const int64_t* pos, float* k_cache, float* v_cache, const float* keymask, int B, int heads,
+                                           int n_tot, float scale, float* out, int ldo, void* stream) {
+    ALDM_CHECK(qkv_part && pos && k_cache && v_cache && keymask && out && B > 0 && heads > 0 && qparts >= 1,
+               "aldm_decode_attention_parts: bad args");
+    ALDM_CHECK(n_tot > 0 && n_tot <= 1024, "aldm_decode_attention_parts: %d cache positions (1..1024 supported)", n_tot);
+    ALDM_CHECK(ldq >= 3 * heads * 64 && ldo >= heads * 64, "aldm_decode_attention_parts: row pitch shorter than the row");
+    ALDM_CHECK(((reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                   (ldo & 3) == 0,
+               "aldm_decode_attention_parts: k_cache / v_cache / out must be 16-byte aligned, ldo a multiple of 4");
+    hipLaunchKernelGGL(decode_attention_kernel, dim3(B * heads), dim3(1024), 0, (hipStream_t)stream, qkv_part, ldq, pos, k_cache,
+                       v_cache, keymask, n_tot, heads, scale, out, ldo, qparts, qstride, qbias);
+    ALDM_LAUNCH_CHECK("aldm_decode_attention_parts");
     return 0;
 }

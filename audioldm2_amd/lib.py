@@ -130,6 +130,15 @@ _SIGS = {
                                      C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_decode_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_decode_gemv_slices": (C.c_int, [C.c_int, C.c_int]),
+    "aldm_decode_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_void_p]),
+    "aldm_decode_reduce_ln": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "aldm_decode_attention_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                              C.c_void_p]),
     "aldm_softmax_rows_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                            C.c_void_p, C.c_int, C.c_void_p]),
     "aldm_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,

@@ -453,6 +453,10 @@ def _kernel_name(d: IgemmDesc, bm: int, bn: int, kg: int = 1, bx: bool = False) 
     (igemm_kernel<BM, BN, WM, WN, PRE, KGRP, UNI, BX>)."""
     if d.a_split:
         nst = _l.load().aldm_igemm_plan_stages(C.byref(d))
+        if nst >= 400:   # halo-patch 3x3 convolution (csrc/igemm_dma_halo.h): 400 + 10 * (8 waves) + weight-ring depth; rocprofv3
+            # appends the patch capacity and the fp16 flag: <BM, BN, ring, WM, parts, MAXCH, F16>
+            w8 = (nst - 400) // 10
+            return f"igemm_dma_halo_kernel<{bm}, {bn}, {(nst - 400) % 10}, {4 if (bm == 256 or w8) else 2}, {d.split_parts or 3}>"
         if nst >= 300:   # operand-stationary kernel for short K (csrc/igemm_dma_os.h): <k-tiles, ring depth, parts, epilogue form>
             epi = 1 if d.epi_mode == _l.EPI_GEGLU else (2 if d.epi_mode == _l.EPI_QKV else 0)   # OS_EPI_GEGLU / _QKV / _PLAIN
             return f"igemm_dma_os_kernel<{d.K // 32}, {nst - 300}, {d.split_parts or 3}, {epi}>"
@@ -1173,6 +1177,85 @@ def decode_attention(qkv: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor
     _l.check(_l.load().aldm_decode_attention(qkv.data_ptr(), 3 * E, pos.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
                                              keymask.data_ptr(), B, heads, n_tot, 0.125 if scale is None else float(scale),
                                              out.data_ptr(), E, _stream()), "decode_attention")
+    return out
+
+
+def decode_gemv(x: torch.Tensor, w_kn: torch.Tensor, *, xbias: Optional[torch.Tensor] = None, xact: int = ACT_NONE) -> torch.Tensor:
+    """Split-K form of the decode GEMV (aldm_decode_gemv): x is [M, K] rows, or [P, M, K] partial slabs of a previous decode_gemv
+    whose sum (+ xbias, through xact) is the operand.  Returns the partial slabs [S, M, N] of x_eff @ w_kn: their sum in slab
+    order (decode_reduce_ln, decode_attention_parts or the next decode_gemv adds them) is the product."""
+    _chk(x, "decode_gemv.x"); _chk(w_kn, "decode_gemv.w")
+    P = 1 if x.dim() == 2 else x.shape[0]
+    M, K = x.shape[-2], x.shape[-1]
+    assert w_kn.dim() == 2 and w_kn.shape[0] == K and 1 <= M <= DECODE_MAX_ROWS
+    N = w_kn.shape[1]
+    lib = _l.load()
+    S = lib.aldm_decode_gemv_slices(K, N)
+    assert S > 0, f"decode_gemv: K = {K} cannot be sliced"
+    if xbias is not None:
+        _chk(xbias, "decode_gemv.xbias")
+        assert xbias.numel() == K
+    y = torch.empty((S, M, N), device=x.device, dtype=torch.float32)
+    _l.check(lib.aldm_decode_gemv(x.data_ptr(), K, P, M * K, _p(xbias), xact, M, K, w_kn.data_ptr(), N, y.data_ptr(), _stream()),
+             "decode_gemv")
+    return y
+
+
+def decode_reduce_ln(part: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None, bias_row: Optional[torch.Tensor] = None,
+                     res: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None,
+                     want_h: bool = True, xn_out: Optional[torch.Tensor] = None):
+    """h = sum of the partial slabs part[S, M, N] (slab order) + bias (row *bias_row of a table when bias_row is given) + res; with
+    ln = (gamma, beta, eps) also LayerNorm(h).  Returns h, (h, xn) or xn (want_h = False); xn_out: a second destination of the
+    normalised rows ([M, N]-shaped view with unit inner stride: a token slot of the generator's output)."""
+    src = part if part is not None else res
+    M, N = src.shape[-2], src.shape[-1]
+    if part is not None:
+        _chk(part, "decode_reduce_ln.part")
+        assert part.dim() == 3
+    for t, nm in ((bias, "bias"), (res, "res")):
+        if t is not None:
+            _chk(t, "decode_reduce_ln." + nm)
+    if res is not None:
+        assert res.shape == (M, N)
+    if bias_row is not None:
+        assert bias_row.is_cuda and bias_row.dtype == torch.int64 and bias_row.numel() == 1 and bias is not None and bias.dim() == 2
+    elif bias is not None:
+        assert bias.numel() == N
+    dev = src.device
+    h = torch.empty((M, N), device=dev, dtype=torch.float32) if want_h else None
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    xn = torch.empty((M, N), device=dev, dtype=torch.float32) if ln is not None else None
+    ldn2 = 0
+    if xn_out is not None:
+        assert ln is not None and xn_out.is_cuda and xn_out.dtype == torch.float32 and xn_out.shape == (M, N) and xn_out.stride(1) == 1
+        ldn2 = xn_out.stride(0)
+    _l.check(_l.load().aldm_decode_reduce_ln(_p(part), 0 if part is None else part.shape[0], M * N, N, _p(bias), _p(bias_row),
+                                             _p(res), N, M, N, _p(h), N, _p(g), _p(b), float(eps), _p(xn), N, _p(xn_out), ldn2,
+                                             _stream()), "decode_reduce_ln")
+    if ln is None:
+        return h
+    return (h, xn) if want_h else xn
+
+
+def decode_attention_parts(qkv_part: torch.Tensor, qbias: Optional[torch.Tensor], pos: torch.Tensor, k_cache: torch.Tensor,
+                           v_cache: torch.Tensor, keymask: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """decode_attention over a sliced c_attn: q | k | v rows = qbias + the sum of the partial slabs qkv_part [S, B, 3 E]."""
+    _chk(qkv_part, "decode_attention_parts.qkv"); _chk(k_cache, "decode_attention_parts.k_cache")
+    _chk(v_cache, "decode_attention_parts.v_cache"); _chk(keymask, "decode_attention_parts.keymask")
+    S, B = qkv_part.shape[0], qkv_part.shape[1]
+    E = heads * 64
+    n_tot = keymask.shape[1]
+    assert qkv_part.shape == (S, B, 3 * E) and keymask.shape[0] == B
+    assert k_cache.shape == (B * heads, n_tot, 64) and v_cache.shape == k_cache.shape
+    assert pos.is_cuda and pos.dtype == torch.int64 and pos.numel() == 1
+    if qbias is not None:
+        _chk(qbias, "decode_attention_parts.qbias")
+        assert qbias.numel() == 3 * E
+    out = torch.empty((B, E), device=qkv_part.device, dtype=torch.float32)
+    _l.check(_l.load().aldm_decode_attention_parts(qkv_part.data_ptr(), 3 * E, S, B * 3 * E, _p(qbias), pos.data_ptr(),
+                                                   k_cache.data_ptr(), v_cache.data_ptr(), keymask.data_ptr(), B, heads, n_tot,
+                                                   0.125 if scale is None else float(scale), out.data_ptr(), E, _stream()),
+             "decode_attention_parts")
     return out
 
 

@@ -203,10 +203,29 @@ class Sequence2AudioMAE(nn.Module):
         Z, n_tot = B * N_HEAD, keymask.shape[1]
         wpe = pk["wpe"].index_select(0, pos).expand(B, 1, N_EMBD).contiguous()
         h = ops.axpby(tok.contiguous(), wpe, 1.0, 1.0).view(B, N_EMBD)
-        fast = getattr(self, "_decode_fast", None)
-        if fast is None:   # (direct callers; generate() reads the switch once per call)
-            fast = os.environ.get("ALDM_SEQGEN_DECODE", "fast") != "general"
-        if B <= ops.DECODE_MAX_ROWS and fast:
+        mode = getattr(self, "_decode_fast", None)
+        if mode is None:   # (direct callers; generate() reads the switch once per call)
+            mode = os.environ.get("ALDM_SEQGEN_DECODE", "split")
+        if B <= ops.DECODE_MAX_ROWS and mode == "split":
+            # round 6: every launch on the whole chip — K cut into slices (one HBM round trip per block), the partial sums handed to
+            # the next launch (csrc/decode.hip, decode_gemv / decode_reduce_ln): 7 launches per block, each a fraction of the
+            # column-tile kernels' time (those give 24 - 96 blocks all of K: one compute unit's memory path per 96 - 393 KB)
+            blocks = pk["blocks"]
+            h, xn = ops.decode_reduce_ln(None, bias=pk["wpe"], bias_row=pos, res=tok.contiguous().view(B, N_EMBD),
+                                         ln=(*blocks[0]["ln1"], LN_EPS))
+            for l, blk in enumerate(blocks):
+                qp = ops.decode_gemv(xn, blk["kn_attn"][0])
+                o = ops.decode_attention_parts(qp, blk["kn_attn"][1], pos, kc[l], vc[l], keymask, N_HEAD)
+                pp = ops.decode_gemv(o, blk["kn_proj"][0])
+                h, xn = ops.decode_reduce_ln(pp, bias=blk["kn_proj"][1], res=h, ln=(*blk["ln2"], LN_EPS))
+                fp = ops.decode_gemv(xn, blk["kn_fc"][0])
+                mp = ops.decode_gemv(fp, blk["kn_mproj"][0], xbias=blk["kn_fc"][1], xact=ACT_GELU_TANH)
+                if l + 1 < len(blocks):
+                    h, xn = ops.decode_reduce_ln(mp, bias=blk["kn_mproj"][1], res=h, ln=(*blocks[l + 1]["ln1"], LN_EPS))
+                else:
+                    xn = ops.decode_reduce_ln(mp, bias=blk["kn_mproj"][1], res=h, ln=(*pk["ln_f"], LN_EPS), want_h=False)
+            return xn.view(B, 1, N_EMBD)
+        if B <= ops.DECODE_MAX_ROWS and mode != "general":
             # B rows per Linear: weight streams, 5 launches per block (csrc/decode.hip) instead of the general path's ~17
             for l, blk in enumerate(pk["blocks"]):
                 qkv = ops.decode_linear(h, *blk["kn_attn"], ln=(*blk["ln1"], LN_EPS))
@@ -239,7 +258,7 @@ class Sequence2AudioMAE(nn.Module):
         if cond_dict is None:
             cond_dict = self.get_input(batch)
         x, mask, P = self.get_input_sequence_and_mask(cond_dict)
-        self._decode_fast = os.environ.get("ALDM_SEQGEN_DECODE", "fast") != "general"   # read once per generation, not per token
+        self._decode_fast = os.environ.get("ALDM_SEQGEN_DECODE", "split")   # "split" | "fast" | "general"; read once per generation
         B, steps = x.shape[0], self.mae_token_num
         n_tot = (P + steps + 3) // 4 * 4
         dev = x.device

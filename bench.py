@@ -368,7 +368,7 @@ def roofline_probe(ld, batch, B):
                            "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}
-    dma = kname.startswith(("igemm_dma_kernel", "igemm_dma_ws_kernel", "igemm_dma_lw_kernel", "igemm_dma_os_kernel"))
+    dma = kname.startswith(("igemm_dma_kernel", "igemm_dma_ws_kernel", "igemm_dma_lw_kernel", "igemm_dma_os_kernel", "igemm_dma_halo_kernel"))
     bx = kname.endswith("true>") or dma                # bf16-split instantiations
     x3 = dma and parts_of.get(kname) == 2              # 2-part images: 3 partial products
     peak = (PEAK_BF16X3_TFLOPS if x3 else PEAK_BF16X6_TFLOPS) if bx else PEAK_F32_MFMA_TFLOPS

@@ -412,6 +412,31 @@ int aldm_decode_linear(const float* x, int ldx, int M, int K, const float* w_kn,
  *   n_tot <= 1024 (GPT-2's n_positions).                                                                                     */
 int aldm_decode_attention(const float* qkv, int ldq, const int64_t* pos, float* k_cache, float* v_cache, const float* keymask,
                           int B, int heads, int n_tot, float scale, float* out, int ldo, void* stream);
+/* ---- the same decode step on the whole chip (ABI v9, round 6): 7 launches per GPT-2 block -----------------------------------
+ * aldm_decode_linear gives one block all of K for its 32 columns: 24 - 96 blocks per launch, each streaming 96 - 393 KB of
+ * weights through one compute unit's memory path.  These entry points cut K into S slices so that every launch covers the chip
+ * with one HBM round trip per block, and hand the partial sums to the NEXT launch instead of reducing them across blocks:
+ *
+ * aldm_decode_gemv_slices(K, N): the S the library uses for a [K, N] weight (K / S rows per slice, a multiple of 32, <= 512;
+ *   column tiles x S >= 256 blocks where K allows) — the caller sizes ypart [S, M, N] with it; 0 = K cannot be sliced.
+ * aldm_decode_gemv: ypart[s][m][n] = sum over slice s of xe[m][k] W[k][n], W = Conv1D's own [K, N] fp32 weight (non-temporal
+ *   loads: read once per token), xe = xact(xbias + x[0] + x[1] + ... + x[xparts-1]) with x[j] = x + j * xstride (partial slabs
+ *   [M, ldx] of the previous aldm_decode_gemv, summed in slab order; xparts = 1, xbias = NULL, xact = NONE: plain rows).
+ * aldm_decode_reduce_ln: per row m: v = part[0][m] + ... + part[nparts-1][m] (slab order; nparts = 0: none) + bias (row
+ *   *bias_row of a [rows, N] table when bias_row != NULL — GPT-2's position embedding at a DEVICE-side position) + res;
+ *   h_out = v (may alias res; NULL: not stored); with ln_gamma: xn (and xn2 when != NULL) = LayerNorm(v) gamma + beta
+ *   (mean, then the centred second moment, biased variance, eps inside the root).  N <= 1024, N % 4 == 0.
+ * aldm_decode_attention_parts: aldm_decode_attention with q | k | v = qbias + the qparts slabs of a sliced c_attn.
+ * Deterministic (fixed slab order), no atomics, no workspace besides the slabs the caller owns.                           */
+int aldm_decode_gemv_slices(int K, int N);
+int aldm_decode_gemv(const float* x, int ldx, int xparts, int64_t xstride, const float* xbias, int xact, int M, int K,
+                     const float* w_kn, int N, float* ypart, void* stream);
+int aldm_decode_reduce_ln(const float* part, int nparts, int64_t pstride, int ldp, const float* bias, const int64_t* bias_row,
+                          const float* res, int ldr, int M, int N, float* h_out, int ldh, const float* ln_gamma,
+                          const float* ln_beta, float ln_eps, float* xn, int ldn, float* xn2, int ldn2, void* stream);
+int aldm_decode_attention_parts(const float* qkv_part, int ldq, int qparts, int64_t qstride, const float* qbias,
+                                const int64_t* pos, float* k_cache, float* v_cache, const float* keymask, int B, int heads,
+                                int n_tot, float scale, float* out, int ldo, void* stream);
 
 /* ---- elementwise ---------------------------------------------------------------------- */
 /* GEGLU gate: y[m, c] = x[m, c] * gelu_erf(x[m, C + c]), x: [M, 2C] (attention.py:42-44)   */

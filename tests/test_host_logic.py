@@ -285,8 +285,33 @@ def _torch_ops_stand_in():
         s = torch.where(keymask[:, None, None, :] != 0, s.view(B, heads, 1, n_tot), torch.full([], float("-inf")))
         return (s.softmax(-1).view(B * heads, 1, n_tot) @ vc).view(B, E)
 
+    # the split-K decode step (round 6): partial slabs [S, M, N] handed from launch to launch (S = 3 here: the stand-in slices K
+    # into thirds, so the hand-over logic — who adds which bias, where the activation sits — is what gets exercised)
+    def decode_gemv(x, w_kn, *, xbias=None, xact=0):
+        xe = x if x.dim() == 2 else x.sum(0)
+        xe = _act(xe + (0 if xbias is None else xbias), xact)
+        K = w_kn.shape[0]
+        return torch.stack([xe[:, i * K // 3:(i + 1) * K // 3] @ w_kn[i * K // 3:(i + 1) * K // 3] for i in range(3)])
+
+    def decode_reduce_ln(part, *, bias=None, bias_row=None, res=None, ln=None, want_h=True, xn_out=None):
+        h = 0 if part is None else part.sum(0)
+        if bias is not None:
+            h = h + (bias[int(bias_row)] if bias_row is not None else bias)
+        if res is not None:
+            h = h + res
+        if ln is None:
+            return h
+        xn = F.layer_norm(h, (h.shape[-1],), ln[0], ln[1], ln[2])
+        if xn_out is not None:
+            xn_out.copy_(xn)
+        return (h, xn) if want_h else xn
+
+    def decode_attention_parts(qkv_part, qbias, pos, kc, vc, keymask, heads):
+        return decode_attention(qkv_part.sum(0) + (0 if qbias is None else qbias), pos, kc, vc, keymask, heads)
+
     return types.SimpleNamespace(
         DECODE_MAX_ROWS=16, decode_linear=decode_linear, decode_attention=decode_attention,
+        decode_gemv=decode_gemv, decode_reduce_ln=decode_reduce_ln, decode_attention_parts=decode_attention_parts,
         pack_conv=lambda w, b=None: PW(w, b), linear=linear,
         layernorm=lambda x, g, b, eps=1e-5: F.layer_norm(x, (x.shape[-1],), g, b, eps),
         axpby=lambda a, b, alpha, beta=0.0: alpha * a + beta * b,
@@ -295,7 +320,7 @@ def _torch_ops_stand_in():
         gemm_packed_batched=lambda a, bp, K, N: a @ bp)
 
 
-@pytest.mark.parametrize("decode", ["fast", "general"])
+@pytest.mark.parametrize("decode", ["split", "fast", "general"])
 @pytest.mark.parametrize("fixture,cfg_name,T", [("seqgen_full_8step_b2", "SEQGEN_FULL", 20),
                                                 ("seqgen_speech_24step_b2", "SEQGEN_SPEECH", 40)])
 def test_sequence_generator_host_logic_matches_reference_fixture(monkeypatch, fixture, cfg_name, T, decode):

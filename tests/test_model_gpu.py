@@ -587,7 +587,8 @@ def test_other_baseline_configs_run_end_to_end(model_name, wave_len):
 
 
 @pytest.mark.parametrize("fixture,B,steps,mode", [("e2e_48k_2step_b1", 1, 2, None), ("e2e_48k_20step_b2", 2, 20, None),
-                                                   ("e2e_48k_5step_b8", 8, 5, "bf16x6"), ("e2e_48k_5step_b8", 8, 5, "bf16x3")])
+                                                   ("e2e_48k_5step_b8", 8, 5, "bf16x6"), ("e2e_48k_5step_b8", 8, 5, "bf16x3"),
+                                                   ("e2e_48k_5step_b8", 8, 5, "f16x3")])
 def test_e2e_48k_matches_reference_generate_batch(fixture, B, steps, mode):
     """BASELINE config 3 (audioldm_48k) end to end against the REAL reference's generate_batch fixtures
     (B=1, 2 DDIM steps; B=2, 20 steps; and — VERDICT r3 next #1b — B=8, 5 steps = the bench batch, in both product modes, so the

@@ -45,7 +45,9 @@ def report(line):
     ("audioldm2-speech-gigaspeech", "e2e_speech_5step_b8", "e2espeech_statedict_keys.json", 8, 5, "bf16x6"),
     ("audioldm2-speech-gigaspeech", "e2e_speech_5step_b8", "e2espeech_statedict_keys.json", 8, 5, "bf16x3"),
     ("audioldm2-full-large-1150k", "e2e_large_5step_b8", "e2elarge_statedict_keys.json", 8, 5, "bf16x6"),
-    ("audioldm2-full-large-1150k", "e2e_large_5step_b8", "e2elarge_statedict_keys.json", 8, 5, "bf16x3")])
+    ("audioldm2-full-large-1150k", "e2e_large_5step_b8", "e2elarge_statedict_keys.json", 8, 5, "bf16x3"),
+    ("audioldm2-speech-gigaspeech", "e2e_speech_5step_b8", "e2espeech_statedict_keys.json", 8, 5, "f16x3"),
+    ("audioldm2-full-large-1150k", "e2e_large_5step_b8", "e2elarge_statedict_keys.json", 8, 5, "f16x3")])
 def test_e2e_speech_and_large_match_reference_generate_batch(model_name, fixture, keys_json, B, steps, mode):
     """BASELINE configs 4 / 5 end to end against the REAL reference's generate_batch fixtures (B=1 at 2 DDIM steps, B=2 at
     20 steps, and — VERDICT r3 next #1b — B=8 at 5 steps = the batch bench.py's `configs` numbers are measured at, in both

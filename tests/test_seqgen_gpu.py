@@ -120,7 +120,78 @@ def test_decode_attention_matches_torch(B, heads, n_tot, pos):
     assert torch.equal(kd.cpu(), kc2) and torch.equal(vd.cpu(), vc2)
 
 
-@pytest.mark.parametrize("decode", ["fast", "general"])
+@pytest.mark.parametrize("M", [1, 4, 5, 8, 16])
+def test_decode_split_k_layer_chain_matches_fp64(M):
+    """The split-K decode step's launches (round 6) chained like one GPT-2 block's: reduce (+ position-embedding row at a DEVICE
+    index) + LayerNorm -> c_attn slices -> [attention's operand = bias + slabs] ; c_proj slices -> reduce + residual + LayerNorm ->
+    c_fc slices -> m_proj reading gelu_new(bias + c_fc's slabs) -> reduce + residual + final LayerNorm into a strided token slot.
+    Each stage against fp64 of the same inputs; repeated launches are bit-identical (fixed slab order, no atomics)."""
+    from audioldm2_amd import ops
+    g = torch.Generator().manual_seed(50 + M)
+    E = 768
+    tok = torch.randn(M, E, generator=g)
+    wpe = torch.randn(20, E, generator=g) * 0.5
+    row = torch.tensor([13], device="cuda")
+    ln = [(torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.1) for _ in range(3)]
+    lin = {n: (torch.randn(k, o, generator=g) / math.sqrt(k), torch.randn(o, generator=g) * 0.3)
+           for n, (k, o) in dict(attn=(E, 3 * E), proj=(E, E), fc=(E, 4 * E), mproj=(4 * E, E)).items()}
+    c = lambda t: t.cuda()
+    lnc = [(c(a), c(b), 1e-5) for a, b in ln]
+    lnd = lambda x, i: F.layer_norm(x, (E,), ln[i][0].double(), ln[i][1].double(), 1e-5)
+    # token + position row -> h0, LN1
+    h0, x1 = ops.decode_reduce_ln(None, bias=c(wpe), bias_row=row, res=c(tok), ln=lnc[0])
+    h0d = tok.double() + wpe[13].double()
+    assert rel(h0, h0d) < 1e-6 and rel(x1, lnd(h0d, 0)) < 2e-6
+    # c_attn slices: the slabs' sum + bias is the projection
+    qp = ops.decode_gemv(x1, c(lin["attn"][0]))
+    S = qp.shape[0]
+    assert S * (3 * E // 32) >= 256 and qp.shape == (S, M, 3 * E)
+    qkv_d = x1.double().cpu() @ lin["attn"][0].double() + lin["attn"][1].double()
+    assert rel(qp.sum(0) + c(lin["attn"][1]), qkv_d) < 2e-6
+    assert torch.equal(qp, ops.decode_gemv(x1, c(lin["attn"][0])))
+    # c_proj slices (operand: plain rows) -> reduce + residual + LN2
+    o = torch.randn(M, E, generator=g)
+    pp = ops.decode_gemv(c(o), c(lin["proj"][0]))
+    h1, x2 = ops.decode_reduce_ln(pp, bias=c(lin["proj"][1]), res=h0, ln=lnc[1])
+    h1d = o.double() @ lin["proj"][0].double() + lin["proj"][1].double() + h0.double().cpu()
+    assert rel(h1, h1d) < 2e-6 and rel(x2, lnd(h1d, 1)) < 3e-6
+    # c_fc slices; m_proj reads gelu_new(bias + slabs)
+    fp = ops.decode_gemv(x2, c(lin["fc"][0]))
+    mp = ops.decode_gemv(fp, c(lin["mproj"][0]), xbias=c(lin["fc"][1]), xact=ops.ACT_GELU_TANH)
+    md = _gelu_new(x2.double().cpu() @ lin["fc"][0].double() + lin["fc"][1].double())
+    h2d = md @ lin["mproj"][0].double() + lin["mproj"][1].double() + h1.double().cpu()
+    slot = torch.zeros(M, 3, E, device="cuda")
+    xf = ops.decode_reduce_ln(mp, bias=c(lin["mproj"][1]), res=h1, ln=lnc[2], want_h=False, xn_out=slot[:, 1])
+    assert rel(xf, lnd(h2d, 2)) < 3e-6
+    assert torch.equal(slot[:, 1], xf) and float(slot[:, 0].abs().max()) == 0.0 and float(slot[:, 2].abs().max()) == 0.0
+    assert torch.equal(mp, ops.decode_gemv(fp, c(lin["mproj"][0]), xbias=c(lin["fc"][1]), xact=ops.ACT_GELU_TANH))
+
+
+@pytest.mark.parametrize("B,heads,n_tot,pos,S", [(3, 12, 40, 17, 4), (8, 12, 600, 599, 2), (1, 12, 36, 35, 1)])
+def test_decode_attention_parts_equals_attention_of_the_summed_rows(B, heads, n_tot, pos, S):
+    """aldm_decode_attention_parts: q | k | v = bias + the slabs of a sliced c_attn, then exactly aldm_decode_attention."""
+    from audioldm2_amd import ops
+    g = torch.Generator().manual_seed(70 + n_tot)
+    E = heads * 64
+    part = torch.randn(S, B, 3 * E, generator=g).cuda()
+    bias = torch.randn(3 * E, generator=g).cuda()
+    kc = torch.randn(B * heads, n_tot, 64, generator=g)
+    vc = torch.randn(B * heads, n_tot, 64, generator=g)
+    km = (torch.rand(B, n_tot, generator=g) > 0.3).float()
+    km[:, pos + 1:] = 0
+    km[:, pos] = 1
+    qkv = part[0].clone()
+    for j in range(1, S):
+        qkv += part[j]
+    qkv += bias
+    p = torch.tensor([pos], device="cuda")
+    k1, v1, k2, v2 = kc.cuda(), vc.cuda(), kc.cuda(), vc.cuda()
+    want = ops.decode_attention(qkv, p, k1, v1, km.cuda(), heads)
+    got = ops.decode_attention_parts(part, bias, p, k2, v2, km.cuda(), heads)
+    assert torch.equal(got, want) and torch.equal(k1, k2) and torch.equal(v1, v2)
+
+
+@pytest.mark.parametrize("decode", ["split", "fast", "general"])
 @pytest.mark.parametrize("fixture,cfg,T", [("seqgen_full_8step_b2", cases.SEQGEN_FULL, 20),
                                            ("seqgen_speech_24step_b2", cases.SEQGEN_SPEECH, 40)])
 def test_sequence_generator_matches_reference_generate(fixture, cfg, T, decode, monkeypatch):

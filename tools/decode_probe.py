@@ -19,7 +19,7 @@ outs = {}
 for B in [int(b) for b in os.environ.get("PROBE_B", "8,4").split(",")]:
     cond = {keys[0]: torch.randn(B, 1, dims[0], generator=g).cuda(),
             keys[1]: [torch.randn(B, T, dims[1], generator=g).cuda(), torch.ones(B, T).cuda()]}
-    for mode in os.environ.get("PROBE_MODES", "general,fast,general,fast").split(","):
+    for mode in os.environ.get("PROBE_MODES", "general,fast,split,fast,split").split(","):
         os.environ["ALDM_SEQGEN_DECODE"] = mode
         m.generate(None, cond_dict=cond)
         torch.cuda.synchronize()
@@ -30,6 +30,9 @@ for B in [int(b) for b in os.environ.get("PROBE_B", "8,4").split(",")]:
         outs[(B, mode)] = out
         print(f"B={B} {steps} tokens after a {T + 5}-position prompt, decode={mode:8s}: {ms:8.1f} ms ({ms / steps:.3f} ms per token)",
               flush=True)
+    if (B, "split") in outs and (B, "general") in outs:
+        a, b = outs[(B, "split")].double(), outs[(B, "general")].double()
+        print(f"B={B}: split vs general, max-norm rel diff over all {steps} tokens: {float((a - b).abs().max() / b.abs().max()):.2e}", flush=True)
     if (B, "fast") not in outs or (B, "general") not in outs:
         continue
     a, b = outs[(B, "fast")].double(), outs[(B, "general")].double()
