@@ -227,10 +227,22 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const float* __r
     if (tid < 64) {
         const float* r = qkv + (int64_t)b * ldq + h * 64 + tid;
         float q = r[0], k = r[E], v = r[2 * E];
-        for (int j = 1; j < qparts; ++j) {   // (round 6) c_attn's K-slices, summed in slab order, then its bias
-            q += r[j * qstride];
-            k += r[j * qstride + E];
-            v += r[j * qstride + 2 * E];
+        for (int j0 = 1; j0 < qparts; j0 += 4) {   // (round 6) c_attn's K-slices, summed in slab order (four loads in flight), then its bias
+            float pq[4], pk[4], pvv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool jon = j0 + jj < qparts;
+                const float* rp = r + (jon ? j0 + jj : 0) * qstride;
+                pq[jj] = jon ? rp[0] : 0.f;
+                pk[jj] = jon ? rp[E] : 0.f;
+                pvv[jj] = jon ? rp[2 * E] : 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                q += pq[jj];
+                k += pk[jj];
+                v += pvv[jj];
+            }
         }
         if (qbias) {
             q += qbias[h * 64 + tid];
@@ -370,9 +382,21 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(const float* __restric
         float xv[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) xv[m] = m < M ? x[(int64_t)m * ldx + k] : 0.f;
-        for (int j = 1; j < xparts; ++j) {
+        // the other slabs four at a time: all of a batch's loads in flight, then added in slab order (a slab past the last adds 0)
+        for (int j0 = 1; j0 < xparts; j0 += 4) {
+            float pv[4][MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) xv[m] += m < M ? x[j * xstride + (int64_t)m * ldx + k] : 0.f;
+            for (int jj = 0; jj < 4; ++jj) {
+                const bool jon = j0 + jj < xparts;
+                const float* xp = x + (jon ? j0 + jj : 0) * xstride + k;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) pv[jj][m] = (jon && m < M) ? xp[(int64_t)m * ldx] : 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xv[m] += pv[jj][m];
+            }
         }
         const float b = xbias ? xbias[k] : 0.f;
 #pragma unroll
@@ -430,8 +454,19 @@ __global__ __launch_bounds__(256) void decode_reduce_ln_kernel(const float* __re
     const bool on = c4 < N;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (on) {
-        if (nparts > 0) v = *reinterpret_cast<const f32x4*>(part + (int64_t)m * ldp + c4);
-        for (int j = 1; j < nparts; ++j) v += *reinterpret_cast<const f32x4*>(part + j * pstride + (int64_t)m * ldp + c4);
+        // eight slabs at a time: a batch's loads all in flight, then added in slab order (a slab past the last adds 0)
+        for (int j0 = 0; j0 < nparts; j0 += 8) {
+            f32x4 pv[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                pv[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j0 + jj < nparts) pv[jj] = *reinterpret_cast<const f32x4*>(part + (j0 + jj) * pstride + (int64_t)m * ldp + c4);
+            }
+            if (j0 == 0) v = pv[0];
+            else v += pv[0];
+#pragma unroll
+            for (int jj = 1; jj < 8; ++jj) v += pv[jj];
+        }
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + (bias_row ? *bias_row * (int64_t)N : 0) + c4);
         if (res) v += *reinterpret_cast<const f32x4*>(res + (int64_t)m * ldr + c4);
         if (h_out) *reinterpret_cast<f32x4*>(h_out + (int64_t)m * ldh + c4) = v;

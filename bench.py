@@ -17,7 +17,7 @@ MFMA partial products of exact 3-part operand splits — fp32-grade (2.4e-7 rms 
 not narrower than the reference's fp32 multiply.  Prints ONE JSON line on rank 0 with the contract keys plus
   `roofline`      dominant igemm instantiation + the attention kernel, measured live with events on the launch stream (the cost of
                   an empty event pair, measured in the same run, is subtracted so the durations compare with rocprofv3's), HBM
-                  traffic from profiles/r05_pmc_traffic_<mode>.json while its source hash matches the running kernels;
+                  traffic from profiles/r06_pmc_traffic_<mode>.json while its source hash matches the running kernels;
   `roofline_tail` VAE decode and HiFi-GAN;
   `fast`          the same job re-run in the opt-in "bf16x3" mode (16-bit operand significands: NARROWER than fp32 — a named
                   sub-record, never the headline);
@@ -55,7 +55,7 @@ PEAK_BF16X6_TFLOPS = round(2500.0 / 6.0, 1)
 PEAK_BF16X3_TFLOPS = round(2500.0 / 3.0, 1)
 def traffic_json(mode):
     """PMC traffic file of the product mode (tools/pmc_traffic.py, stamped with the kernel-source hash)."""
-    return os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{mode}.json")
+    return os.path.join(ROOT, "profiles", f"r06_pmc_traffic_{mode}.json")
 # ("f16x3" mixes three-product fp16 launches — ~2/3 of a UNet pass's FLOPs — with six-product bf16 ones: its step is divided by the
 #  HEADLINE mode's peak, so that the two fractions compare)
 MODE_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x6": PEAK_BF16X6_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS, "f16x3": PEAK_BF16X6_TFLOPS}
@@ -64,9 +64,10 @@ MODE_DTYPE = {
     "bf16x6": "f32 storage/accumulate; each product = 6 bf16 MFMA partial products of exact 3-part operand splits (fp32-grade)",
     "bf16x3": "f32 storage/accumulate; DMA-fed GEMM and attention products = 3 bf16 MFMA partial products of (hi, mid) operand "
               "parts rounded to nearest (16-bit operand significands); all other contractions bf16x6",
-    "f16x3": "f32 storage/accumulate; GEMMs fed by a GroupNorm / LayerNorm (ResBlock convs, proj_in, q/k/v, GEGLU: ~2/3 of the UNet's "
-             "FLOPs) = 3 fp16 MFMA partial products of (hi, lo) parts of power-of-two scaled operands (22 of 24 significand bits, "
-             "0.65-0.7x the fp32 MFMA's error vs fp64); every other contraction, attention included, bf16x6",
+    "f16x3": "f32 storage/accumulate; contractions whose operands have an a-priori bound (GroupNorm / LayerNorm-fed convs and "
+             "projections, q/k/v, self-attention QK^T and PV and its to_out, GEGLU and FF-out: ~80 % of the UNet's FLOPs) = 3 fp16 MFMA "
+             "partial products of (hi, lo) parts of power-of-two scaled operands (22 of 24 significand bits, 0.61-0.72x the fp32 MFMA's "
+             "error vs fp64); every other contraction bf16x6",
 }
 # algorithmic GFLOP per sample of the tail stages (FlopCounterMode on the reference modules)
 VAE_DECODE_GFLOP = {"audioldm2-full": 670.5, "audioldm2-full-large-1150k": 670.5, "audioldm2-speech-gigaspeech": 670.5,
@@ -575,11 +576,12 @@ def main():
                 "bf16x3": "bf16x3 (opt-in fast mode): fp32 operands and accumulation; the DMA-fed GEMMs and attention keep (hi, mid) of "
                           "every operand, rounded to nearest (16 significant bits — NARROWER than fp32), 3 bf16 MFMA partial products "
                           "per product (4.4e-6 rms per contraction); all other launches bf16x6",
-                "f16x3": "f16x3 (opt-in, round 6): fp32 operands and accumulation; the GEMMs whose A operand comes out of a GroupNorm / "
-                         "LayerNorm read 2-part IEEE-fp16 images of power-of-two scaled operands (scale from the normalisation's a-priori "
-                         "bound; weights by their maximum) and run hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 — 3 matrix "
-                         "instructions per fp32 product, 22 of 24 significand bits per operand, measured 0.65-0.7x the fp32 MFMA's error "
-                         "(profiles/r06_f16x3_accuracy.txt); all other launches bf16x6",
+                "f16x3": "f16x3 (opt-in, round 6): fp32 operands and accumulation; every contraction whose operands have an a-priori "
+                         "bound — GEMMs fed by a GroupNorm / LayerNorm, the q/k/v they produce, the self-attention's QK^T and PV, its "
+                         "output into to_out, the GEGLU output into FF-out — reads 2-part IEEE-fp16 images of power-of-two scaled operands "
+                         "(scales from the bounds; weights by their maximum) and runs hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: 3 "
+                         "matrix instructions per fp32 product, 22 of 24 significand bits per operand, measured 0.61-0.72x the fp32 MFMA's "
+                         "error (profiles/r06_f16x3_accuracy.txt); launches without a bound (residual stream, raw activations) bf16x6",
                 "f32": "f32: fp32 MFMA (exact fp32 products)"}[mode]
 
     def step_metrics(dst, mode):
@@ -661,7 +663,7 @@ def main():
                 try:
                     if not args.no_step_probe:
                         step_metrics(st, sub_mode)
-                    if not args.no_roofline and sub_mode == "bf16x3":
+                    if not args.no_roofline:
                         st["roofline"] = roofline_probe(ld, make_batch_for_text_to_audio("synthetic prompt", batchsize=B), B)
                 except Exception as e:  # pragma: no cover
                     st["probe_error"] = str(e)
