@@ -36,7 +36,7 @@ __device__ __forceinline__ float max_across_halves(float x) {
 
 // Exact 3-way split of 8 fp32 values (x = hi + mid + lo, each part the top 16 bits of an fp32) into three bf16x8
 // MFMA operands; element j of an operand is x[j].  Same arithmetic as the igemm engine's A-side split
-// (igemm_kernel.h).
+// (igemm_kernel.h, docs/experiments_r1-r6.md §3.1b).
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&part)[3]) {
     unsigned u[3][8];
 #pragma unroll

@@ -38,7 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float gelu_erf_fast(float v) {
     // 16 VALU instructions (round 4: ~23 — the library is built with -ffp-contract=off, so the Horner steps are explicit FMAs here,
     // and the sign select is folded away: 0.5 v (1 + erf z) = max(v, 0) - 0.5 |v| poly(t) exp(-z^2) for either sign of v).  In the
-    // GEGLU epilogues every one of these instructions is issue time the matrix pipe does not overlap.
+    // GEGLU epilogues every one of these instructions is issue time the matrix pipe does not overlap (docs/experiments_r1-r6.md §3.1c).
     const float a = fabsf(v) * 0.70710678118654752440f;                       // |z|
     const float t = __frcp_rn(__builtin_fmaf(0.3275911f, a, 1.0f));
     float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);

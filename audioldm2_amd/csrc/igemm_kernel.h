@@ -1,7 +1,7 @@
 // igemm_kernel.h — the implicit-GEMM convolution / GEMM kernel, on the fp32 MFMA (v_mfma_f32_32x32x2_f32) or,
 // with BX = true, on the bf16 matrix cores with every fp32 product evaluated as six bf16 partial products of
 // exact 3-way operand splits (v_mfma_f32_32x32x16_bf16, "BF16x6"; the default path — see the notes at Frag /
-// the BX branch of the K loop below and DESIGN.md §3.1b).
+// the BX branch of the K loop below and docs/experiments_r1-r6.md §3.1b).
 //
 //   out[m, n] = epi( sum_k A[m, k] * W[k, n] ),  m = (b, oh, ow), k = (kh, kw, ci)
 //

@@ -392,7 +392,7 @@ def roofline_probe(ld, batch, B):
     attn = None
     if ag:
         (ah, aLq, aLk, amask), (an, afl, asec) = max(ag.items(), key=lambda kv: kv[1][2])
-        attn = {"bound": "mfma (measured: MFMAs alone 57 us of a 94-97 us launch at the power-capped clock; + K / V streamed per wave from L2 85; + softmax / operand-split VALU work, DESIGN §3.2)", "kernel": "aldm::attention_d32_*",
+        attn = {"bound": "mfma (measured: MFMAs alone 57 us of a 94-97 us launch at the power-capped clock; + K / V streamed per wave from L2 85; + softmax / operand-split VALU work, docs/experiments_r1-r6.md §3.2)", "kernel": "aldm::attention_d32_*",
                 "dominant": {"heads": ah, "Lq": aLq, "Lk": aLk, "masked": bool(amask), "launches_per_unet_pass": an,
                              "avg_launch_us": round(asec / an * 1e6, 2), "achieved": round(afl / asec / 1e12, 2)},
                 "achieved": round(a_fl / a_s / 1e12, 2), "unit": "TFLOP/s", "peak": apeak, "frac": round(a_fl / a_s / 1e12 / apeak, 4),

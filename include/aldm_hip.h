@@ -15,7 +15,7 @@
  *     (thread local).  Host wrappers turn that into a Python RuntimeError, mirroring the
  *     reference's plain-exception convention (e.g. openaimodel.py:858-860 asserts).
  *   - operands, accumulators and every stored tensor are IEEE fp32; HOW an fp32 x fp32 product of a contraction is
- *     evaluated depends on the matrix-core mode (DESIGN.md §6): "f32" = v_mfma_f32_32x32x2_f32 (exact fp32 products,
+ *     evaluated depends on the matrix-core mode (DESIGN.md §4): "f32" = v_mfma_f32_32x32x2_f32 (exact fp32 products,
  *     bit-identical to an fmaf chain); "bf16x6" (the DEFAULT) = 6 bf16 MFMA partial products of exact 3-part operand
  *     splits (fp32 grade, 2.4e-7 rms vs fp64); "bf16x3" (opt-in fast mode for launches over pre-split operands and for
  *     attention) = 3 partial products of (hi, mid) parts rounded to nearest: 16 significant bits per operand, 4.4e-6 rms.
@@ -141,7 +141,7 @@ typedef struct aldm_igemm_desc {
     /* ABI v4: optional bf16-split image of the packed weights (aldm_pack_split_bf16).  When set (packed
        weights, stride_w == 0) the product runs on the bf16 matrix cores as fp32 = 6 bf16 partial products
        of exact 3-way operand splits with fp32 accumulation ("BF16x6": per-product error 0.7 * 2^-24 on average, <= 2^-21 worst case, i.e. fp32
-       grade; see DESIGN.md §3.1) instead of the fp32 MFMA.  NULL => fp32 MFMA.                         */
+       grade; see DESIGN.md §3) instead of the fp32 MFMA.  NULL => fp32 MFMA.                         */
     const void* w_split;
     int32_t hint_mma;      /* tuned table: 1 = fp32 MFMA even when w_split is set, 0 = automatic          */
     int32_t hint_stages;   /* DMA-fed kernel: LDS ring depth (0 = automatic); 100 + depth = the persistent wave-
@@ -283,7 +283,7 @@ int aldm_split_rows_f16(const float* x1, const float* x2, int C1, int C2, int64_
  *   conv:      [N, Cin, KH, KW] (Conv2d / Conv1d with KH = 1),  linear: KH = KW = 1
  *   transposed=1: ConvTranspose1d layout [Cin, N, KW]; phase/stride select the polyphase
  *   taps kw = phase + j*stride (j = 0..T-1, T = ceil(KWfull/stride)), stored flipped so the
- *   phase runs as an ordinary conv with PW = T-1.
+ *   phase runs as an ordinary conv with PW = T-1 (polyphase decomposition, ops.pack_convtr1d).
  * dst has ceil(K/4) * Npad * 4 floats, Npad = round_up(N, 32), K = KH*KWeff*Cin.           */
 int aldm_pack_weight(const float* src, float* dst, int N, int Cin, int KH, int KW,
                      int transposed, int phase, int stride, void* stream);

@@ -3,7 +3,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 This piece has no counterpart in the reference (which multiplies in fp32 through ATen): it is the checker for HOW the
 HIP kernels evaluate the reference's fp32 products on the bf16 matrix cores (audioldm2_amd/csrc/igemm_kernel.h,
-DESIGN.md §3.1b), i.e. that the evaluation is fp32-grade and that the weight image has the documented layout.
+docs/experiments_r1-r6.md §3.1b), i.e. that the evaluation is fp32-grade and that the weight image has the documented layout.
   * split3        x = hi + mid + lo exactly, each part the top 16 bits of an fp32 (truncation)
   * product6      a*b ~ hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi (exact partial products, here summed in
                   fp64; the MFMA accumulates them in fp32, which is the fp32 kernels' accumulation error too)

@@ -1,4 +1,4 @@
-"""CPU checks of the bf16-split arithmetic the HIP igemm kernels use by default (oracle/bf16x6.py):
+"""CPU checks of the bf16-split arithmetic the HIP igemm kernels use by default (oracle/bf16x6.py, docs/experiments_r1-r6.md §3.1b):
 the operand split is exact, six partial products reproduce an fp32 product to <= 2^-21 relative in the worst case and
 to about one fp32 rounding on average, and a whole
 contraction evaluated that way is at least as close to the exact result as an fp32 GEMM."""
