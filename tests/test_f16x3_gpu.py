@@ -277,6 +277,28 @@ def test_stress_operands(ops, gain, offset, wkind):
     assert rel_err(uncl(y), ref) < 1e-4
 
 
+def test_out_of_bound_values_saturate_instead_of_overflowing(ops):
+    """The seat belt behind the a-priori bounds: a producer handed a scale that is too large for its data (which the bounds rule out:
+    here it is forced through the C entry point) writes +-65504, never inf / NaN, and values inside the range are unaffected."""
+    from audioldm2_amd import lib as L
+    M, C = 64, 128
+    x = torch.randn(M, C, generator=g(5))
+    ga, be = torch.ones(C), torch.zeros(C)
+    ref = F.layer_norm(x, (C,), ga, be, 1e-5).double()
+    for scale in (2.0 ** 20, 2.0 ** 15):      # |scale * value| up to ~4e6 (all saturate) / ~1.2e5 (the values beyond +-2 saturate)
+        so = ops.SplitT.empty((M, C), torch.device("cuda"), f16_scale=scale)
+        xd, gd, bd = x.cuda(), ga.cuda(), be.cuda()     # (held: the entry point takes raw pointers)
+        L.check(L.load().aldm_layernorm_split_f16(xd.data_ptr(), None, so.data_ptr(), M, C, gd.data_ptr(), bd.data_ptr(),
+                                                  1e-5, scale, torch.cuda.current_stream().cuda_stream), "layernorm_split_f16")
+        torch.cuda.synchronize()
+        h = so.data.view(torch.float16).float().cpu()
+        assert bool(torch.isfinite(h).all())
+        got = (h[:, :, 0].double() + h[:, :, 1].double()).reshape(M, C)
+        want = (ref * scale).clamp(-65504.0, 65504.0)
+        assert float((got - want).abs().max()) <= 65504.0 * 2.0 ** -20
+        assert float(got.abs().max()) == 65504.0          # something did saturate in both cases
+
+
 def test_mixed_graph_of_a_resblock_and_a_transformer_block_matches_the_default_mode(ops):
     """A UNet in small (tests' tiny config) evaluated in f16x3 and in bf16x6 on the same weights and inputs: same result to the
     fp32-grade UNet bar — the mode changes which matrix instruction runs, not what is computed."""

@@ -17,14 +17,14 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 idx = [i for i, r in enumerate(rows) if "ddim_step_indexed" in r[2]]
-steps = []
-for a, b in zip(idx[:-1], idx[1:]):
-    seg = rows[a + 1:b + 1]
-    # a replayed step: no weight packing (first eager pass), no VAE / vocoder kernels (job boundary)
-    if len(seg) > 200 and not any("pack_" in r[2] or "igemm_kernel<" in r[2] or "copyBuffer" in r[2] for r in seg):
-        steps.append(seg)
-if not steps:
+segs = [rows[a + 1:b + 1] for a, b in zip(idx[:-1], idx[1:])]
+# a replayed step: no weight packing (the first eager pass), and the dispatch count every replay has (a job boundary also holds the
+# VAE / vocoder kernels; the drawer thread's noise upload may add one or two copyBuffer dispatches)
+segs = [s for s in segs if len(s) > 200 and not any("pack_" in r[2] for r in s)]
+if not segs:
     sys.exit("no replayed DDIM step found")
+med = sorted(len(s) for s in segs)[len(segs) // 2]
+steps = [s for s in segs if abs(len(s) - med) <= 3]
 steps = steps[len(steps) // 2:]   # the timed job's
 
 
