@@ -274,16 +274,15 @@ class Sequence2AudioMAE(nn.Module):
         from .ddim import GraphStepper
         toks = torch.empty((B, steps, N_EMBD), device=dev)
         toks[:, 0:1] = tok
-        st = {"tok": tok.clone(), "pos": torch.full((1,), P, device=dev, dtype=torch.long),
-              "slot": torch.ones((1,), device=dev, dtype=torch.long)}
+        ps = torch.tensor([P, 1], device=dev, dtype=torch.long)      # (position, output slot): advanced together, one launch per token
+        st = {"tok": tok.clone(), "pos": ps[0:1], "slot": ps[1:2]}
 
         def step(e=st):
             keymask.index_fill_(1, e["pos"], 1.0)        # the token joins the sequence (its own key is visible to it)
             new = self._decode_one(e["tok"], e["pos"], kc, vc, keymask)
             e["tok"].copy_(new)
             toks.index_copy_(1, e["slot"], new)
-            e["pos"] += 1
-            e["slot"] += 1
+            ps.add_(1)
         run = GraphStepper(step, use_graph=x.is_cuda and steps >= self.GRAPH_MIN_STEPS and
                            os.environ.get("ALDM_NO_GRAPH", "0") != "1")
         try:

@@ -773,7 +773,7 @@ def test_shared_cfg_prefix_ends_at_the_first_transformer_with_a_context():
 
 
 def test_committed_traffic_records_describe_the_igemm_sources_in_the_tree():
-    """profiles/r05_pmc_traffic_*.json (HBM bytes per launch of the igemm kernels, which bench.py quotes as roofline.traffic) are
+    """profiles/r06_pmc_traffic_*.json (HBM bytes per launch of the igemm kernels, which bench.py quotes as roofline.traffic) are
     stamped with the hash of the igemm sources they were collected on; bench.py drops them as stale when neither that nor the
     all-sources hash matches.  The committed records must describe the committed igemm sources."""
     import json
@@ -781,8 +781,8 @@ def test_committed_traffic_records_describe_the_igemm_sources_in_the_tree():
     from audioldm2_amd.lib import source_hash
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert source_hash("igemm") != source_hash()
-    for mode in ("bf16x6", "bf16x3"):
-        with open(os.path.join(root, "profiles", f"r05_pmc_traffic_{mode}.json")) as f:
+    for mode in ("bf16x6", "f16x3", "bf16x3"):
+        with open(os.path.join(root, "profiles", f"r06_pmc_traffic_{mode}.json")) as f:
             tj = json.load(f)
         assert tj["igemm_source_hash"] == source_hash("igemm"), mode
         assert tj["kernels"], mode
