@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -153,7 +155,7 @@ class Generator(nn.Module):
     # 87 % of the vocoder's FLOPs (L * C^2 per stage: 1.34, 1.34, 0.67, 0.34, 0.17 G for the 16 kHz generator) and are matrix-pipe
     # bound; the 64- / 32-channel stages are HBM bound (K = 3 * C is short) and an extra operand-image pass would cost more
     # than the faster products give back.
-    DMA_MIN_CHANNELS = 128
+    DMA_MIN_CHANNELS = int(os.environ.get("ALDM_HIFIGAN_DMA_MIN", "128"))   # (A/B: tools/hifigan_probe.py)
 
     def _stage_dma(self, pk, i, u, k, x):
         """One upsampling stage with every leaky_relu applied by the PRODUCER of the conv's operand image instead of the conv's

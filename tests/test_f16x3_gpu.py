@@ -318,3 +318,33 @@ def test_mixed_graph_of_a_resblock_and_a_transformer_block_matches_the_default_m
         ops.set_mma(prev)
         unet.drop_step_caches()
     assert rel_err(e16, e6) < 5e-6
+
+
+@pytest.mark.parametrize("seed,span", [(1, 1.5), (2, 1.5), (3, 2.5)])
+def test_unet_with_per_tensor_gains_matches_the_default_mode(ops, seed, span):
+    """Random-init networks are tame: every layer has the same magnitude.  A trained checkpoint does not, and the a-priori scales of
+    this mode are functions of the parameters (max|gamma|, ||beta||, the weights' column norms).  Every floating parameter tensor of
+    the tiny UNet gets its own gain 2^u, u uniform in [-span, span] (norm gains and biases included: bounds from 0.18x to 5.7x their
+    random-init size, attention logits up to 30x): the mode must still agree with bf16x6 at the fp32-grade UNet bar, with finite output."""
+    from audioldm2_amd.unet import UNetModel
+    from oracle import cases, weights
+    cfg = cases.UNET_TINY
+    unet = UNetModel(**cfg)
+    sd = weights.make_state_dict(weights.shapes_of(unet), seed=0)
+    gen = g(100 + seed)
+    for k, v in sd.items():
+        if torch.is_floating_point(v):
+            sd[k] = v * float(2.0 ** ((torch.rand(1, generator=gen).item() * 2.0 - 1.0) * span))
+    unet.load_state_dict(sd)
+    x, t, ctxs, masks, _ = cases.unet_inputs(cfg, 2, 16, 8)
+    kw = dict(context_list=[c.cuda() for c in ctxs], context_attn_mask_list=[m.cuda() for m in masks])
+    e16 = unet(x.cuda(), t.cuda(), **kw).clone()
+    assert bool(torch.isfinite(e16).all())
+    prev = ops.set_mma("bf16x6")
+    try:
+        unet.drop_step_caches()
+        e6 = unet(x.cuda(), t.cuda(), **kw).clone()
+    finally:
+        ops.set_mma(prev)
+        unet.drop_step_caches()
+    assert rel_err(e16, e6) < 1e-5
