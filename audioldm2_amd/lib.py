@@ -197,6 +197,19 @@ def source_hash(family: str = "all") -> str:
     return h.hexdigest()[:16]
 
 
+def tuning_hash() -> str:
+    """16 hex digits over the shipped geometry tables (audioldm2_amd/tuning/*.json).  Per-launch counter records carry it next to
+    source_hash: an instantiation's launch set — hence its AVERAGE bytes per launch — follows the table that routes geometries to it."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "tuning", "*.json"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Load libaldm_hip.so once; fail loudly when it has not been built."""
     global _lib

@@ -350,7 +350,7 @@ def roofline_probe(ld, batch, B):
     traffic, traffic_src = None, None
     TRAFFIC_JSON = traffic_json(ops.MMA_MODE)
     if os.path.exists(TRAFFIC_JSON):
-        from audioldm2_amd.lib import source_hash
+        from audioldm2_amd.lib import source_hash, tuning_hash
         with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
         # rocprofv3 spells trailing template arguments the Python-side name does not carry (igemm_dma_kernel's DROP = false, the
@@ -369,6 +369,9 @@ def roofline_probe(ld, batch, B):
             traffic = ent["hbm_bytes_per_launch"]
             traffic_src = {"file": "profiles/" + os.path.basename(TRAFFIC_JSON), "source_hash": tj["source_hash"],
                            "igemm_source_hash": tj.get("igemm_source_hash"),
+                           # the launch set of an instantiation follows the geometry tables: false = the record averages over
+                           # the launches another table routed to this kernel (same kernel code)
+                           "same_geometry_tables": tj.get("tuning_hash") == tuning_hash(),
                            "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}
@@ -487,7 +490,7 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
     # the baseline is the best of a sweep, with the winning count reported as `cores`
     sweep = {}
     ncpu = os.cpu_count() or 8
-    for th in [t for t in (16, 32, 64) if t <= ncpu] or [ncpu]:
+    for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
         torch.set_num_threads(th)
         ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, 1, 1.0, o.buffers["alphas_cumprod"])  # warm
         t0 = time.time()

@@ -32,8 +32,8 @@ def main():
     fetch = collect(sys.argv[1], "FETCH_SIZE")
     write = collect(sys.argv[2], "WRITE_SIZE")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from audioldm2_amd.lib import source_hash
-    out = {"source_hash": source_hash(), "igemm_source_hash": source_hash("igemm"),
+    from audioldm2_amd.lib import source_hash, tuning_hash
+    out = {"source_hash": source_hash(), "igemm_source_hash": source_hash("igemm"), "tuning_hash": tuning_hash(),
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two runs) of " +
                      (sys.argv[4] if len(sys.argv) > 4 else
                       "ALDM_NO_GRAPH=1 python bench.py --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline"),
