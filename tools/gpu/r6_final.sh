@@ -33,6 +33,11 @@ ALDM_NO_GRAPH=1 timeout -k 5 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 ALDM_NO_GRAPH=1 timeout -k 5 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM --kernel-include-regex "$KRE" -f csv -d /tmp/pmc_sq2 -- python $R/bench.py $Q < /dev/null > /dev/null 2>&1
 cd $R
 python tools/pmc_sq_table.py /tmp/pmc_sq1 /tmp/pmc_sq2 > $O/pmc_sq_bf16x6.txt 2>&1; head -30 $O/pmc_sq_bf16x6.txt
+cd /tmp
+ALDM_NO_GRAPH=1 timeout -k 5 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-include-regex "$KRE" -f csv -d /tmp/pmc_sq1h -- python $R/bench.py --mma f16x3 $Q < /dev/null > /dev/null 2>&1
+ALDM_NO_GRAPH=1 timeout -k 5 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM --kernel-include-regex "$KRE" -f csv -d /tmp/pmc_sq2h -- python $R/bench.py --mma f16x3 $Q < /dev/null > /dev/null 2>&1
+cd $R
+python tools/pmc_sq_table.py /tmp/pmc_sq1h /tmp/pmc_sq2h > $O/pmc_sq_f16x3.txt 2>&1; head -12 $O/pmc_sq_f16x3.txt
 rm -f gpurun_out/parity_report.txt $O/err_log.tsv
 ( time ALDM_ERR_LOG=$R/$O/err_log.tsv timeout -k 5 3000 python -m pytest tests/ -q -m gpu < /dev/null ) > $O/gpu_suite.log 2>&1; echo "gpu suite rc=$?"; tail -5 $O/gpu_suite.log | cut -c1-200
 cp gpurun_out/parity_report.txt $O/parity_report.txt
