@@ -13,7 +13,9 @@
 //    octet XOR-swizzled by (pixel >> 2) & 3) per wave and k-tile instead of NP * BM / (16 * waves).  Rows above / below the
 //    image come from the zero page;
 //  * a tap is a SHIFT of the fragment-read address: output pixel pt (tile-local, row-major) reads patch pixel
-//    pp = pt + kh * W + kw - 1; the left / right zero padding (kw = 0 at column 0, kw = 2 at column W - 1) reads a zero slot.
+//    pp = pt + kh * W + kw - 1; the left / right zero padding (kw = 0 at column 0, kw = 2 at column W - 1) reads a zero slot — the one
+//    of the SAME 16-byte bank group as the slot it replaces (one shared zero slot cost 10-15 % LDS bank-conflict cycles: it broke the
+//    permutation below).
 //    The ds_read_b128 lane groups {0-3, 12-15, 20-27} + shift are a permutation of 0 .. 15 mod 16 for EVERY shift, so the
 //    swizzled layout stays conflict free for all nine taps and any W;
 //  * the weights stream exactly as in igemm_dma_kernel (NSTB-deep ring of [4 octets x NP parts][BN] k-tiles, 1 KB pieces), in
@@ -195,7 +197,7 @@ void igemm_dma_halo_kernel(const IgemmK p) {
             const int cc = (pt[i] & (W - 1)) + c_kw - 1;
             const unsigned off = (unsigned)(pp >> 4) * (NP * 1024) + (unsigned)(pp & 15) * 64 + (unsigned)((((pp >> 2) & 3) ^ lh) << 4);
             const unsigned real = (unsigned)(c_buf * PATCH * 16) + off;
-            const unsigned zslot = (unsigned)(Z0 * 16 + lh * 16);
+            const unsigned zslot = (unsigned)(Z0 * 16) + (off & 0xF0u);   // the zero slot of the SAME 16-byte bank group as the real slot
             aaddr_n[i] = (unsigned)cc < (unsigned)W ? real : zslot;
         }
     };

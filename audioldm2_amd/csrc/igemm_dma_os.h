@@ -156,7 +156,11 @@ void igemm_dma_os_kernel(const IgemmK p) {
             simg = nullptr;
         }
     }
-    const int er = lane >> 2, ec = (lane & 3) * 4;        // plain path: this lane's row / column quad of a staged 16x16 tile
+    // plain path: this lane's row / column quad of a staged 16x16 tile.  The tile is staged with its 4x4 row index transposed (row
+    // 4 lg + i at position 4 i + lg): the four k-groups of one ds_write_b32 then hit four different 64-byte bank quarters (in row
+    // order they are 256 bytes apart — the same 16 banks, a 4-way conflict on every accumulator write), and lane l reads position
+    // l >> 2 = row 4 ((l >> 2) & 3) + (l >> 4), still one contiguous KB per wave
+    const int er = ((lane >> 2) & 3) * 4 + (lane >> 4), ec = (lane & 3) * 4;
     const int ncol = n0 + wave * 16 + ec;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (!geglu && d.bias) {
@@ -168,7 +172,10 @@ void igemm_dma_os_kernel(const IgemmK p) {
     // GEGLU: lane column lc < 8 -> value column, lc >= 8 -> its gate column; outputs leave through lanes of an 8-column tile
     const int g_pcol = n0 + g64 * 64 + j8 * 8 + (lc < 8 ? lc : 32 + (lc - 8));
     const float g_bias = (geglu && d.bias && g_pcol < d.N) ? d.bias[g_pcol] : 0.f;
-    const int g_er = lane >> 1, g_ec = (lane & 1) * 4;
+    // (staged like the plain tile: row 4 lg + i of a 16-row half at position 4 i + lg, so that the k-groups of one write do not share
+    //  banks; lane l reads position l >> 1)
+    const int g_pos = lane >> 1, g_ec = (lane & 1) * 4;
+    const int g_er = (g_pos & 16) + (g_pos & 3) * 4 + ((g_pos & 15) >> 2);
     const int g_ncol_o = ((n0 + g64 * 64) >> 1) + j8 * 8 + g_ec;
     const bool g_cok = n0 + g64 * 64 + j8 * 8 + g_ec < d.N;
 
@@ -225,8 +232,8 @@ void igemm_dma_os_kernel(const IgemmK p) {
                 const float g0 = __builtin_bit_cast(   // gelu(gate of row tile 0) from the gate lanes
                     float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
                 if (lc < 8) {
-                    stg[(lg * 4 + i) * 8 + lc] = x0 * g0;
-                    stg[(16 + lg * 4 + i) * 8 + lc] = x1 * gz;
+                    stg[(i * 4 + lg) * 8 + lc] = x0 * g0;
+                    stg[(16 + i * 4 + lg) * 8 + lc] = x1 * gz;
                 }
             }
 #else
@@ -238,10 +245,10 @@ void igemm_dma_os_kernel(const IgemmK p) {
                     const float xg = __builtin_bit_cast(
                         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
                     const float y = x * gelu_erf_fast(xg);
-                    if (lc < 8) stg[(rt * 16 + lg * 4 + i) * 8 + lc] = y;
+                    if (lc < 8) stg[(rt * 16 + i * 4 + lg) * 8 + lc] = y;
                 }
 #endif
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[g_er * 8 + g_ec]);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[g_pos * 8 + g_ec]);
             const int m = m0 + g_er;
             if (m < p.M && g_cok) {
                 if (d.out) *reinterpret_cast<f32x4*>(d.out + (int64_t)m * d.ldo + g_ncol_o) = v;
@@ -285,8 +292,8 @@ void igemm_dma_os_kernel(const IgemmK p) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) stg[(lg * 4 + i) * 16 + lc] = acc[rt][i];
-                v[rt] = *reinterpret_cast<const f32x4*>(&stg[er * 16 + ec]);
+                for (int i = 0; i < 4; ++i) stg[(i * 4 + lg) * 16 + lc] = acc[rt][i];
+                v[rt] = *reinterpret_cast<const f32x4*>(&stg[(lane >> 2) * 16 + ec]);
                 v[rt] += bias4;
                 if (has_res) v[rt] += resv[rt];
                 v[rt] *= d.alpha;
