@@ -375,6 +375,11 @@ def roofline_probe(ld, batch, B):
                            "launches": ent["launches"],
                            "fetch_bytes_per_launch_corrected": ent["fetch_bytes_per_launch_corrected"],
                            "write_bytes_per_launch": ent["write_bytes_per_launch"]}
+    def kpeak(k):   # nominal fp32-equivalent peak of an instantiation, TFLOP/s
+        k_dma = k.startswith(("igemm_dma_kernel", "igemm_dma_ws_kernel", "igemm_dma_lw_kernel", "igemm_dma_os_kernel", "igemm_dma_halo_kernel"))
+        if not (k.endswith("true>") or k_dma):
+            return PEAK_F32_MFMA_TFLOPS
+        return PEAK_BF16X3_TFLOPS if (k_dma and parts_of.get(k) == 2) else PEAK_BF16X6_TFLOPS
     dma = kname.startswith(("igemm_dma_kernel", "igemm_dma_ws_kernel", "igemm_dma_lw_kernel", "igemm_dma_os_kernel", "igemm_dma_halo_kernel"))
     bx = kname.endswith("true>") or dma                # bf16-split instantiations
     x3 = dma and parts_of.get(kname) == 2              # 2-part images: 3 partial products
@@ -421,8 +426,14 @@ def roofline_probe(ld, batch, B):
         "all_igemm_tflops": round(tot_fl / tot_s / 1e12, 2),
         "all_igemm_launches": sum(v[0] for v in agg.values()),
         "all_igemm_ms": round(tot_s * 1e3, 3),
-        "top_kernels": [{"kernel": k, "launches": v[0], "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1)}
-                        for k, v in by_kernel],
+        "top_kernels": [{"kernel": k, "launches": v[0], "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
+                         "frac": round(v[1] / v[2] / 1e12 / kpeak(k), 4)} for k, v in by_kernel],
+        # the whole igemm population of the pass against ITS roofline: the time the launches would take at their own peaks
+        # (3 or 6 products per multiply-add, fp32 MFMA for the register-staged fp32 forms) over the time they took
+        "all_igemm_frac": round(sum(v[1] / (kpeak(k) * 1e12) for k, v in agg.items()) / tot_s, 4),
+        # a dominant instantiation of short launches is a latency-bound population (dependent launches in a replayed graph have a
+        # ~5 us floor, their weight slabs are HBM-cold): `frac` prices it against the matrix pipe all the same
+        "dominant_is_short_launches": bool(sec / n < 20e-6),
         "traffic_over_algorithmic": round(traffic / (minb / n), 3) if traffic else None,
         "attention": attn,
     }

@@ -786,3 +786,60 @@ def test_committed_traffic_records_describe_the_igemm_sources_in_the_tree():
             tj = json.load(f)
         assert tj["igemm_source_hash"] == source_hash("igemm"), mode
         assert tj["kernels"], mode
+
+
+def test_os_epilogue_staging_is_a_conflict_free_transpose():
+    """csrc/igemm_dma_os.h, plain / q / k epilogue (round 6): lane (lc = l & 15, lg = l >> 4) holds rows 4 lg + i (i = 0..3) of column lc of a
+    16x16 accumulator tile and stages them at float index (4 i + lg) * 16 + lc; lane l then reads the float4 at position l >> 2, columns
+    4 (l & 3)..+3, and stores it as row er = 4 ((l >> 2) & 3) + (l >> 4).  Checked here on the index arithmetic alone: every (row, col) is
+    written once, a reader gets the row it stores, and the 64 lanes of one ds_write_b32 hit 64 different 4-byte banks (row-major staging
+    put the four k-groups on the same 16 banks).  Same for the GEGLU form's 32 x 8 tile (lanes lc < 8 write, lane l reads position l >> 1)."""
+    tile = {}
+    for i in range(4):
+        banks = set()
+        for l in range(64):
+            lc, lg = l & 15, l >> 4
+            idx = (i * 4 + lg) * 16 + lc
+            assert idx not in tile
+            tile[idx] = (4 * lg + i, lc)
+            banks.add(idx % 64)
+        assert len(banks) == 64, i
+        assert len({((lg * 4 + i) * 16 + lc) % 64 for lg in range(4) for lc in range(16)}) == 16   # the layout it replaces
+    for l in range(64):
+        er, ec = ((l >> 2) & 3) * 4 + (l >> 4), (l & 3) * 4
+        for c in range(4):
+            assert tile[(l >> 2) * 16 + ec + c] == (er, ec + c)
+    assert sorted({((l >> 2) & 3) * 4 + (l >> 4) for l in range(64)}) == list(range(16))
+    g = {}
+    for i in range(4):
+        for half in range(2):
+            banks = set()
+            for l in range(64):
+                lc, lg = l & 15, l >> 4
+                if lc < 8:
+                    idx = (half * 16 + i * 4 + lg) * 8 + lc
+                    assert idx not in g
+                    g[idx] = (half * 16 + 4 * lg + i, lc)
+                    banks.add(idx % 64)
+            assert len(banks) == 32
+    for l in range(64):
+        pos, ec = l >> 1, (l & 1) * 4
+        er = (pos & 16) + (pos & 3) * 4 + ((pos & 15) >> 2)
+        for c in range(4):
+            assert g[pos * 8 + ec + c] == (er, ec + c)
+
+
+def test_halo_zero_slot_keeps_the_bank_group_of_the_slot_it_replaces():
+    """csrc/igemm_dma_halo.h: a lane whose tap falls into the left / right zero padding reads the zero region at byte offset
+    (off & 0xF0) instead of the patch slot at `off` — the same 16-byte bank group (bits 4..7 of the LDS byte address), so the 16 lanes of a
+    ds_read_b128 phase keep touching 16 different groups; the k-step XOR (1 << 5) and the part offset (q KB) stay inside the NP KB zero
+    region."""
+    for NP in (2, 3):
+        for pp in range(0, 400):
+            for lh in (0, 1):
+                off = (pp >> 4) * (NP * 1024) + (pp & 15) * 64 + ((((pp >> 2) & 3) ^ lh) << 4)
+                z = off & 0xF0
+                for step in (0, 1):
+                    assert ((z ^ (step << 5)) >> 4) & 15 == ((off ^ (step << 5)) >> 4) & 15
+                    for q in range(NP):
+                        assert 0 <= (z ^ (step << 5)) + q * 1024 < NP * 1024
