@@ -127,7 +127,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations reported under `configs`")
     ap.add_argument("--configs-steps", type=int, default=1, help="timed jobs per other configuration (after one warm-up job)")
     ap.add_argument("--no-f16x3", dest="no_f16x3", action="store_true", help="skip the f16x3 re-run reported under `f16x3`")
-    ap.add_argument("--fast-steps", type=int, default=1, help="timed jobs of the fast re-run (after one warm-up job)")
+    ap.add_argument("--fast-steps", type=int, default=2, help="timed jobs of each sub-mode re-run (fast, f16x3; after one warm-up job)")
     ap.add_argument("--no-conditioners", action="store_true", help="skip the conditioner stacks reported under `conditioners`")
     ap.add_argument("--no-api-default", action="store_true", help="skip the n_candidate_gen_per_text = 3 job (`api_default`)")
     ap.add_argument("--no-replicas", action="store_true",
