@@ -471,8 +471,11 @@ static int groupnorm_launch(const float* x1, const float* x2, int B, int P, int 
     hipStream_t st = (hipStream_t)stream;
     static const int64_t fused_max = [] {   // A/B override: largest sample (elements) handled by the one-launch form
         const char* e = getenv("ALDM_GN_FUSED_MAX");
-        return e ? (int64_t)atoll(e) : (int64_t)1 << 20;
+        return e ? (int64_t)atoll(e) : (int64_t)1 << 17;
     }();
+    // (2^17 elements per sample since round 6: round 2 chose 2^20 on isolated launches; INSIDE the replayed bf16x6 step the level-1
+    //  slabs — 1024 pixels x 256-640 channels — are 0.05-0.12 ms per step faster on the chunked statistics + finalize + split_rows form,
+    //  f16x3 indifferent: profiles/r06_step_ab_gn_fused_max.txt)
     // group slices per sample: enough blocks to cover the chip (>= 256 / B), each owning gpb = G / gs whole groups
     int gs = 1;
     while (gs < G && gs * B < 256 && G % (gs * 2) == 0) gs *= 2;

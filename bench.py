@@ -509,23 +509,24 @@ def cpu_baseline(B_unused, ddim_steps_sample, total_steps):
         sweep[th] = (time.time() - t0) / 2
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
-    t0 = time.time()
-    z = ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, ddim_steps_sample, 1.0, o.buffers["alphas_cumprod"])
-    t_loop = time.time() - t0
+    # the host is shared with the launcher (and, under rocprofv3, the profiler): the sample is timed twice and the better run quoted.
+    # (The sweep's 2-step bursts are NOT used for the value: they come out up to 2x faster per step than a sustained run.)
+    t_loop = None
+    for _ in range(2):
+        t0 = time.time()
+        z = ddim_sample(o.apply_model, (1, 8, 256, 16), cond, uncond, 3.5, ddim_steps_sample, 1.0, o.buffers["alphas_cumprod"])
+        t_loop = min(t_loop, time.time() - t0) if t_loop is not None else time.time() - t0
     t0 = time.time()
     mel = vae_decode(o.sd, o.dd, z / o.scale_factor, prefix="first_stage_model.")
     t_dec = time.time() - t0
     t0 = time.time()
     hifigan_forward(o.sd, o.hcfg, mel.squeeze(1).permute(0, 2, 1), prefix="first_stage_model.vocoder.")
     t_voc = time.time() - t0
-    # the host is shared with the launcher and the profiler: the longer sample can come out SLOWER than the sweep's two steps at the
-    # same thread count — quote the best per-step time observed at the winning count (a slower CPU number would flatter the GPU)
-    step_s = min(t_loop / ddim_steps_sample, sweep[threads])
+    step_s = t_loop / ddim_steps_sample
     total = step_s * total_steps + t_dec + t_voc
     return {"value": round((163872 / 16000.0) / total, 5), "unit": "audio-s/s", "cores": threads, "kind": "port",
             "sample": (f"CPU oracle (torch fp32, best of a thread sweep: {threads} of {ncpu} host threads), B=1: "
-                       f"{ddim_steps_sample} DDIM steps timed ({t_loop / ddim_steps_sample * 1e3:.0f} ms/step; best of that and the sweep's "
-                       f"{sweep[threads] * 1e3:.0f} used: {step_s*1e3:.0f}) x{total_steps} extrapolated + "
+                       f"{ddim_steps_sample} DDIM steps timed twice, the better run quoted ({step_s*1e3:.0f} ms/step) x{total_steps} extrapolated + "
                        f"VAE decode {t_dec:.2f}s + vocoder {t_voc:.2f}s"),
             "unet_step_ms": round(step_s * 1e3, 1),
             "thread_sweep_ms_per_step": {str(k): round(v * 1e3) for k, v in sweep.items()}}
