@@ -843,3 +843,18 @@ def test_halo_zero_slot_keeps_the_bank_group_of_the_slot_it_replaces():
                     assert ((z ^ (step << 5)) >> 4) & 15 == ((off ^ (step << 5)) >> 4) & 15
                     for q in range(NP):
                         assert 0 <= (z ^ (step << 5)) + q * 1024 < NP * 1024
+
+
+def test_committed_traffic_records_carry_the_shipped_geometry_tables_stamp():
+    """An instantiation's AVERAGE bytes per launch follows the table that routes geometries to it: the round-6 traffic records are
+    stamped with lib.tuning_hash() next to the source hashes, and bench.py reports `same_geometry_tables` from it.  The committed
+    records must have been collected under the committed tables."""
+    import json
+    import os
+    from audioldm2_amd.lib import tuning_hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = tuning_hash()
+    assert len(h) == 16 and h == tuning_hash()
+    for mode in ("bf16x6", "f16x3", "bf16x3"):
+        with open(os.path.join(root, "profiles", f"r06_pmc_traffic_{mode}.json")) as f:
+            assert json.load(f).get("tuning_hash") == h, mode
